@@ -1,0 +1,249 @@
+// oracle/ref_driver.cpp -- TEST INFRASTRUCTURE ONLY (never shipped, never on the product path).
+//
+// A thin extern "C" driver over the *untouched* reference Serial C++ sources.  It is compiled
+// by oracle/Makefile against the sources where they lie under /root/reference/Code/Serial/src
+// (nothing from the reference is copied into this repository) into oracle/_ref/libpapof_ref.so.
+// It exists only in the build container: it pins the CPU restatement (papof_oracle.c) and
+// generates the golden vectors in tests/golden/ (see tests/golden/make_golden.py).
+//
+// All images cross this boundary in the reference's own layout: row-major, channel-interleaved
+// (HWC) IEEE fp64, exactly what DImage::pData holds (src/Image.h:36-56).
+//
+// Every entry point below calls a public static of the reference:
+//   OpticalFlow::Coarse2FineFlow   src/OpticalFlow.cpp:735-903
+//   OpticalFlow::SmoothFlowSOR     src/OpticalFlow.cpp:238-536
+//   OpticalFlow::getDxs            src/OpticalFlow.cpp:80-122
+//   OpticalFlow::warpFL            src/OpticalFlow.cpp:154-159
+//   OpticalFlow::Laplacian         src/OpticalFlow.cpp:641-690
+//   OpticalFlow::im2feature        src/OpticalFlow.cpp:911-961
+//   GaussianPyramid::ConstructPyramidLevels  src/GaussianPyramid.cpp:79-108
+//   Image<T>::imresize / GaussianSmoothing / warpImageBicubicRef / threshold  src/Image.h
+#include "OpticalFlow.h"
+#include "GaussianPyramid.h"
+#include <cstring>
+#include <map>
+#include <string>
+#include <cstdio>
+#include <unistd.h>
+#include <fcntl.h>
+
+namespace {
+
+void load(DImage& d, const double* src, int h, int w, int c, bool rgb = false) {
+    d.allocate(w, h, c);
+    std::memcpy(d.pData, src, sizeof(double) * (size_t)h * w * c);
+    if (rgb) d.setColorType(0);  // RGB, as src/Coarse2FineFlowWrapper.cpp:21-28 does
+}
+void store(double* dst, const DImage& d) {
+    std::memcpy(dst, d.data(), sizeof(double) * (size_t)d.width() * d.height() * d.nchannels());
+}
+void set_lappara(int n) {
+    // src/OpticalFlow.cpp:773-775
+    OpticalFlow::LapPara.allocate(n);
+    for (int i = 0; i < OpticalFlow::LapPara.dim(); i++) OpticalFlow::LapPara[i] = 0.02;
+}
+
+// The reference prints progress on stdout (src/OpticalFlow.cpp:787-788,832-834); silence it.
+struct Quiet {
+    int saved;
+    Quiet() {
+        fflush(stdout);
+        std::cout.flush();
+        saved = dup(1);
+        int nul = open("/dev/null", O_WRONLY);
+        dup2(nul, 1);
+        close(nul);
+    }
+    ~Quiet() {
+        fflush(stdout);
+        std::cout.flush();
+        dup2(saved, 1);
+        close(saved);
+    }
+};
+
+const char* kKeys[10] = {"Allocation",         "Construction",  "Phase1_Generate", "Phase2_Derivatives",
+                         "Phase3_PsiData",     "Phase4_LinearSystem", "Phase5_SOR", "Phase6_Update",
+                         "PostProcessing",     "Total C++ Execution"};
+}  // namespace
+
+extern "C" {
+
+// Full reference call.  timing[10] follows the std::map key order of src/OpticalFlow.cpp:850-860.
+int ref_coarse2fine_flow(const double* im1, const double* im2, int h, int w, int c, int levels, double* vx,
+                         double* vy, double* warpI2, double* timing) {
+    Quiet q;
+    DImage I1, I2, VX, VY, W2;
+    load(I1, im1, h, w, c, true);
+    load(I2, im2, h, w, c, true);
+    std::map<std::string, std::string> t;
+    OpticalFlow::Coarse2FineFlow(&t, VX, VY, W2, I1, I2, levels);
+    store(vx, VX);
+    store(vy, VY);
+    store(warpI2, W2);
+    if (timing)
+        for (int i = 0; i < 10; i++) timing[i] = t.count(kKeys[i]) ? atof(t[kKeys[i]].c_str()) : -1.0;
+    return 0;
+}
+
+// Same level loop as src/OpticalFlow.cpp:784-842 but with the iteration schedule as arguments
+// (n_outer + k*outer_step, n_sor + k*sor_step at level k), composed from the reference's own
+// public statics.  With (7,1,1,30,3) it must reproduce ref_coarse2fine_flow bit for bit
+// (checked by tests/golden/make_golden.py); config-4's "3 outer / 30 SOR" is (3,0,1,30,0).
+int ref_coarse2fine_flow_sched(const double* im1, const double* im2, int h, int w, int c, int levels,
+                               double alpha, double ratio, int n_outer, int outer_step, int n_inner,
+                               int n_sor, int sor_step, double* vx, double* vy, double* warpI2) {
+    Quiet q;
+    DImage Im1, Im2;
+    load(Im1, im1, h, w, c, true);
+    load(Im2, im2, h, w, c, true);
+    GaussianPyramid P1, P2;
+    P1.ConstructPyramidLevels(Im1, ratio, levels);
+    P2.ConstructPyramidLevels(Im2, ratio, levels);
+    set_lappara(c + 2);
+    DImage Image1, Image2, WarpImage2, VX, VY, W2;
+    for (int k = P1.nlevels() - 1; k >= 0; k--) {
+        int width = P1.Image(k).width(), height = P1.Image(k).height();
+        OpticalFlow::im2feature(Image1, P1.Image(k));
+        OpticalFlow::im2feature(Image2, P2.Image(k));
+        if (k == P1.nlevels() - 1) {
+            VX.allocate(width, height);
+            VY.allocate(width, height);
+            WarpImage2.copyData(Image2);
+        } else {
+            VX.imresize(width, height);
+            VX.Multiplywith(1 / ratio);
+            VY.imresize(width, height);
+            VY.Multiplywith(1 / ratio);
+            OpticalFlow::warpFL(WarpImage2, Image1, Image2, VX, VY);
+        }
+        OpticalFlow::SmoothFlowSOR(Image1, Image2, WarpImage2, VX, VY, alpha, n_outer + k * outer_step, n_inner,
+                                   n_sor + k * sor_step);
+    }
+    Im2.warpImageBicubicRef(Im1, W2, VX, VY);
+    W2.threshold();
+    store(vx, VX);
+    store(vy, VY);
+    store(warpI2, W2);
+    return 0;
+}
+
+// Pyramid: dims[2*i] = width, dims[2*i+1] = height; data = levels concatenated (HWC).
+// Call with data == NULL first to get dims.
+int ref_pyramid(const double* im, int h, int w, int c, double ratio, int levels, int* dims, double* data) {
+    DImage I;
+    load(I, im, h, w, c, true);
+    GaussianPyramid P;
+    P.ConstructPyramidLevels(I, ratio, levels);
+    size_t off = 0;
+    for (int i = 0; i < P.nlevels(); i++) {
+        dims[2 * i] = P.Image(i).width();
+        dims[2 * i + 1] = P.Image(i).height();
+        size_t n = (size_t)P.Image(i).width() * P.Image(i).height() * c;
+        if (data) std::memcpy(data + off, P.Image(i).data(), n * sizeof(double));
+        off += n;
+    }
+    return P.nlevels();
+}
+
+int ref_gaussian_smoothing(const double* im, int h, int w, int c, double sigma, int fsize, double* out) {
+    DImage I, O;
+    load(I, im, h, w, c);
+    I.GaussianSmoothing(O, sigma, fsize);
+    store(out, O);
+    return 0;
+}
+
+int ref_resize_ratio(const double* im, int h, int w, int c, double ratio, int* dw, int* dh, double* out) {
+    DImage I, O;
+    load(I, im, h, w, c);
+    I.imresize(O, ratio);
+    *dw = O.width();
+    *dh = O.height();
+    if (out) store(out, O);
+    return 0;
+}
+
+int ref_resize_wh(const double* im, int h, int w, int c, int dw, int dh, double* out) {
+    DImage I;
+    load(I, im, h, w, c);
+    I.imresize(dw, dh);
+    store(out, I);
+    return 0;
+}
+
+// returns number of feature channels
+int ref_im2feature(const double* im, int h, int w, int c, double* out) {
+    DImage I, F;
+    load(I, im, h, w, c, true);
+    OpticalFlow::im2feature(F, I);
+    if (out) store(out, F);
+    return F.nchannels();
+}
+
+int ref_warpFL(const double* im1, const double* im2, const double* vx, const double* vy, int h, int w, int c,
+               double* out) {
+    DImage I1, I2, VX, VY, O;
+    load(I1, im1, h, w, c);
+    load(I2, im2, h, w, c);
+    load(VX, vx, h, w, 1);
+    load(VY, vy, h, w, 1);
+    OpticalFlow::warpFL(O, I1, I2, VX, VY);
+    store(out, O);
+    return 0;
+}
+
+int ref_getDxs(const double* im1, const double* im2, int h, int w, int c, double* imdx, double* imdy,
+               double* imdt) {
+    DImage I1, I2, DX, DY, DT;
+    load(I1, im1, h, w, c);
+    load(I2, im2, h, w, c);
+    OpticalFlow::getDxs(DX, DY, DT, I1, I2);
+    store(imdx, DX);
+    store(imdy, DY);
+    store(imdt, DT);
+    return 0;
+}
+
+int ref_laplacian(const double* in, const double* weight, int h, int w, double* out) {
+    DImage I, Wt, O;
+    load(I, in, h, w, 1);
+    load(Wt, weight, h, w, 1);
+    OpticalFlow::Laplacian(O, I, Wt);
+    store(out, O);
+    return 0;
+}
+
+// One SmoothFlowSOR call (the whole IRLS loop of one pyramid level).  warp, u, v are in/out.
+int ref_smoothflow_sor(const double* im1, const double* im2, double* warp, double* u, double* v, int h, int w,
+                       int c, double alpha, int n_outer, int n_inner, int n_sor) {
+    Quiet q;
+    DImage I1, I2, W2, U, V;
+    load(I1, im1, h, w, c);
+    load(I2, im2, h, w, c);
+    load(W2, warp, h, w, c);
+    load(U, u, h, w, 1);
+    load(V, v, h, w, 1);
+    set_lappara(c);
+    OpticalFlow::SmoothFlowSOR(I1, I2, W2, U, V, alpha, n_outer, n_inner, n_sor);
+    store(warp, W2);
+    store(u, U);
+    store(v, V);
+    return 0;
+}
+
+// Final warp of the RGB originals: src/OpticalFlow.cpp:841-842.
+int ref_bicubic_warp(const double* im1, const double* im2, const double* vx, const double* vy, int h, int w, int c,
+                     double* out) {
+    DImage I1, I2, VX, VY, O;
+    load(I1, im1, h, w, c, true);
+    load(I2, im2, h, w, c, true);
+    load(VX, vx, h, w, 1);
+    load(VY, vy, h, w, 1);
+    I2.warpImageBicubicRef(I1, O, VX, VY);
+    O.threshold();
+    store(out, O);
+    return 0;
+}
+
+}  // extern "C"
