@@ -1,0 +1,20 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: > 15 s of CPU work; enabled by PAPOF_SLOW=1")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from _libs import OracleLib
+    return OracleLib()

@@ -1,0 +1,203 @@
+"""Golden cases for the hot path: each case is a function `lib -> {name: ndarray}` evaluated
+
+* by tests/golden/make_golden.py with RefLib (the untouched reference, build container only) to
+  produce tests/golden/golden.npz, and
+* by tests/test_oracle_golden.py with OracleLib (our CPU restatement) to pin the oracle.
+
+Inputs are derived only from the committed frames (tests/golden/frames, data files of the
+reference's benchmark set images_New/HoChiMinhTraffic_10FPS_*) and seeded numpy generators, so the
+test re-creates them without the reference.  The reference has no tests or golden vectors of its
+own; its only known-answer artefact is the testLaplacian matrix, reproduced in
+tests/test_oracle_golden.py.
+"""
+import hashlib
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FRAMES = os.path.join(HERE, "frames")
+SIZES = {"240": (135, 240), "480": (270, 480), "960": (540, 960), "1920": (1080, 1920)}
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+
+
+def load_frame_u8(res, idx):
+    from PIL import Image
+    return np.array(Image.open(os.path.join(FRAMES, res, "frame_%05d.jpg" % idx)))
+
+
+def load_pair(res):
+    """Decode exactly as Code/Serial/OpticalFlowCalculation.py:65-70 does (PIL -> float64 / 255)."""
+    a = load_frame_u8(res, 1).astype(np.float64) / 255.0
+    b = load_frame_u8(res, 2).astype(np.float64) / 255.0
+    return a, b
+
+
+def subsample(a, target=20000):
+    f = np.ascontiguousarray(a, dtype=np.float64).ravel()
+    stride = max(1, -(-f.size // target))
+    return f[::stride].copy()
+
+
+def smooth_field(rng, h, w, amp):
+    """Smooth random field (bilinear blow-up of a coarse normal grid); deterministic for a seed."""
+    gh, gw = h // 16 + 2, w // 16 + 2
+    g = rng.standard_normal((gh, gw)) * amp
+    yy = np.linspace(0, gh - 1.001, h)
+    xx = np.linspace(0, gw - 1.001, w)
+    y0, x0 = yy.astype(int), xx.astype(int)
+    fy, fx = (yy - y0)[:, None], (xx - x0)[None, :]
+    a = g[y0][:, x0]
+    b = g[y0][:, x0 + 1]
+    c = g[y0 + 1][:, x0]
+    d = g[y0 + 1][:, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def features5(im):
+    """A 5-channel stand-in for im2feature output built with numpy only."""
+    return np.ascontiguousarray(
+        np.concatenate([im, im[..., :1] - im[..., 1:2], im[..., 1:2] - im[..., 2:3]], axis=2))
+
+
+# ----------------------------------------------------------------------------------------------
+# end-to-end cases
+# ----------------------------------------------------------------------------------------------
+def _e2e(res, levels):
+    def run(lib):
+        a, b = load_pair(res)
+        vx, vy, wi, _ = lib.coarse2fine_flow(a, b, levels)
+        return {"vx": vx, "vy": vy, "warpI2": wi}
+    return run
+
+
+def _sched(res, levels, sched):
+    def run(lib):
+        a, b = load_pair(res)
+        vx, vy, wi = lib.coarse2fine_flow_sched(a, b, levels, 0.012, 0.75, *sched)
+        return {"vx": vx, "vy": vy, "warpI2": wi}
+    return run
+
+
+def _gray(res, levels):
+    def run(lib):
+        a, b = load_pair(res)
+        a = np.ascontiguousarray(a.mean(axis=2, keepdims=True))
+        b = np.ascontiguousarray(b.mean(axis=2, keepdims=True))
+        vx, vy, wi, _ = lib.coarse2fine_flow(a, b, levels)
+        return {"vx": vx, "vy": vy, "warpI2": wi}
+    return run
+
+
+# ----------------------------------------------------------------------------------------------
+# stage cases (240x135 frames)
+# ----------------------------------------------------------------------------------------------
+def stage_pyramid(lib):
+    a, _ = load_pair("240")
+    out = {}
+    for i, lv in enumerate(lib.pyramid(a, 0.75, 7)):  # levels 5,6 take the i>n branch
+        out["L%d" % i] = lv
+    for i, lv in enumerate(lib.pyramid(a[:40, :50], 0.5, 3)):
+        out["r05_L%d" % i] = lv
+    return out
+
+
+def stage_gaussian(lib):
+    a, _ = load_pair("240")
+    return {"s1_f3": lib.gaussian_smoothing(a, 1.0, 3), "s133_f3": lib.gaussian_smoothing(a, 4.0 / 3 - 1e-16, 3),
+            "f0": lib.gaussian_smoothing(a, 0.33, 0), "one_ch": lib.gaussian_smoothing(a[..., :1], 0.7, 2)}
+
+
+def stage_resize(lib):
+    a, _ = load_pair("240")
+    rng = np.random.default_rng(7)
+    fl = smooth_field(rng, 101, 180, 2.0)[..., None]
+    return {"down075": lib.resize_ratio(a, 0.75), "down_pow": lib.resize_ratio(a, 0.75 ** 3),
+            "up_wh": lib.resize_wh(fl, 240, 135), "up_wh_odd": lib.resize_wh(fl[:56, :101], 135, 75),
+            "tiny": lib.resize_wh(fl[:2, :4], 5, 2)}
+
+
+def stage_im2feature(lib):
+    a, b = load_pair("240")
+    return {"rgb": lib.im2feature(a), "gray": lib.im2feature(np.ascontiguousarray(b[..., 1:2])),
+            "tiny": lib.im2feature(np.ascontiguousarray(a[:2, :4])),
+            "other_c": lib.im2feature(np.ascontiguousarray(a[..., :2]))}
+
+
+def _flow(seed, h, w, amp):
+    rng = np.random.default_rng(seed)
+    vx = smooth_field(rng, h, w, amp)
+    vy = smooth_field(rng, h, w, amp)
+    vx[:3, :] -= 4.0  # force some samples outside the image (the copy-Im1 branch)
+    vy[:, -3:] += 4.0
+    vx[5, 7] = 0.0  # exact-integer coordinates
+    vy[5, 7] = 0.0
+    return np.ascontiguousarray(vx), np.ascontiguousarray(vy)
+
+
+def stage_warp(lib):
+    a, b = load_pair("240")
+    f1, f2 = features5(a), features5(b)
+    vx, vy = _flow(11, 135, 240, 2.5)
+    return {"warp5": lib.warpFL(f1, f2, vx, vy), "warp3": lib.warpFL(a, b, vx * 3, vy * 3),
+            "bicubic": lib.bicubic_warp(a, b, vx, vy), "bicubic_big": lib.bicubic_warp(a, b, vx * 4, vy * 4)}
+
+
+def stage_getdxs(lib):
+    a, b = load_pair("240")
+    f1, f2 = features5(a), features5(b)
+    dx, dy, dt = lib.getDxs(f1, f2)
+    tx, ty, tt = lib.getDxs(np.ascontiguousarray(f1[:3, :4]), np.ascontiguousarray(f2[:3, :4]))
+    return {"imdx": dx, "imdy": dy, "imdt": dt, "tiny_dx": tx, "tiny_dy": ty, "tiny_dt": tt}
+
+
+def stage_laplacian(lib):
+    rng = np.random.default_rng(3)
+    x = smooth_field(rng, 41, 67, 1.0)
+    wgt = rng.uniform(0.5, 50.0, (41, 67))
+    return {"lap": lib.laplacian(x, wgt), "row": lib.laplacian(x[:1], wgt[:1]), "col": lib.laplacian(x[:, :1], wgt[:, :1])}
+
+
+def stage_smoothflow(lib):
+    a, b = load_pair("240")
+    f1 = np.ascontiguousarray(features5(a)[::2, ::2])
+    f2 = np.ascontiguousarray(features5(b)[::2, ::2])
+    h, w, _ = f1.shape
+    z = np.zeros((h, w))
+    w1, u1, v1 = lib.smoothflow_sor(f1, f2, f2, z, z, 0.012, 3, 1, 10)
+    w2, u2, v2 = lib.smoothflow_sor(f1, f2, f2, z, z, 0.012, 2, 2, 7)
+    g1 = np.ascontiguousarray(f1[:9, :12])
+    g2 = np.ascontiguousarray(f2[:9, :12])
+    w3, u3, v3 = lib.smoothflow_sor(g1, g2, g2, np.zeros((9, 12)), np.zeros((9, 12)), 0.012, 2, 1, 5)
+    return {"warp": w1, "u": u1, "v": v1, "inner2_warp": w2, "inner2_u": u2, "inner2_v": v2, "tiny_warp": w3,
+            "tiny_u": u3, "tiny_v": v3}
+
+
+CASES = {
+    "e2e_240_L1": _e2e("240", 1),
+    "e2e_240_L2": _e2e("240", 2),
+    "e2e_240_L5": _e2e("240", 5),
+    "e2e_240_L15": _e2e("240", 15),  # reaches 4x2-pixel levels (Code/Serial/TestSuite.py:91 uses 15)
+    "e2e_480_L5": _e2e("480", 5),
+    "e2e_960_L5": _e2e("960", 5),
+    "e2e_1920_L5": _e2e("1920", 5),
+    "cfg4_240_L5": _sched("240", 5, (3, 0, 1, 30, 0)),  # BASELINE.json config-4 schedule: 3 outer / 30 SOR
+    "cfg4_480_L5": _sched("480", 5, (3, 0, 1, 30, 0)),
+    "cfg4_1920_L5": _sched("1920", 5, (3, 0, 1, 30, 0)),
+    "inner2_240_L3": _sched("240", 3, (4, 1, 2, 12, 3)),
+    "gray_240_L3": _gray("240", 3),
+    "stage_pyramid": stage_pyramid,
+    "stage_gaussian": stage_gaussian,
+    "stage_resize": stage_resize,
+    "stage_im2feature": stage_im2feature,
+    "stage_warp": stage_warp,
+    "stage_getdxs": stage_getdxs,
+    "stage_laplacian": stage_laplacian,
+    "stage_smoothflow": stage_smoothflow,
+}
+
+# cases whose oracle run takes > ~15 s on one core; exercised by the CPU suite only when PAPOF_SLOW=1
+SLOW = {"e2e_1920_L5", "cfg4_1920_L5"}
