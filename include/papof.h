@@ -1,0 +1,174 @@
+/* include/papof.h -- C ABI of the MI355X-native coarse-to-fine optical-flow hot path.
+ *
+ * Drop-in boundary.  This library replaces everything beneath the reference's only FFI seam:
+ *
+ *   Code/Serial/coarse2Fine.pxd:8-12 and Code/Serial/src/Coarse2FineFlowWrapper.h:12-15
+ *       map<string,string> Coarse2FineFlowWrapper(double* vx, double* vy, double* warpI2,
+ *                                                 const double* Im1, const double* Im2,
+ *                                                 int pyramidLevels, int h, int w, int c);
+ *   (Code/Parallel/coarse2Fine.pxd:11 inserts `int nCores` after pyramidLevels)
+ *
+ * which Code/Serial/pyflow.pyx:61-66 calls with caller-allocated, C-contiguous float64 buffers
+ * (Im1, Im2, warpI2: h*w*c, channel-interleaved; vx, vy: h*w).  The C++ std::map return value cannot
+ * cross a C ABI, so the ten timers the reference publishes (src/OpticalFlow.cpp:850-860) come back in
+ * `timing_sec[10]`, in the map's sorted key order (PAPOF_TIMING_KEYS); the Python/Cython side formats
+ * them into the dict of strings pyflow.coarse2fine_flow returns.
+ *
+ * Conventions: plain pointers and sizes only; no exceptions cross the boundary; every function returns
+ * PAPOF_OK (0) or a negative PAPOF_E* code; the caller owns every buffer; the library retains nothing
+ * between calls except the device arena inside a papof_handle.  The compute path is HIP on gfx950 only:
+ * there is NO CPU fallback -- without a usable GPU every compute entry point returns PAPOF_ENODEVICE.
+ */
+#ifndef PAPOF_H
+#define PAPOF_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAPOF_VERSION 100 /* 0.1.0 */
+
+enum {
+    PAPOF_OK = 0,
+    PAPOF_EINVAL = -1,     /* NULL pointer, non-positive size, pyramid_levels < 1 (UB in the reference:
+                              src/GaussianPyramid.cpp:87-88), unsupported parameter */
+    PAPOF_ENODEVICE = -2,  /* no gfx950 device / HIP runtime error at start-up */
+    PAPOF_ENOMEM = -3,     /* device or host allocation failed */
+    PAPOF_EDEVICE = -4,    /* a HIP call failed mid-flight (papof_last_error() has the text) */
+    PAPOF_ETIMEOUT = -5    /* a bounded device-side wait expired (exact-order SOR progress counters) */
+};
+
+/* Order of the SOR sweep (src/OpticalFlow.cpp:458-505). */
+enum {
+    PAPOF_SOR_EXACT = 0,    /* the reference's in-place sweep->row->column order, bit-compatible results */
+    PAPOF_SOR_REDBLACK = 1, /* in-place two-colour sweeps: throughput mode, NOT reference parity      */
+    PAPOF_SOR_JACOBI = 2    /* every cell from the previous sweep: correctness-gate mode (config 2)   */
+};
+
+/* Solver parameters.  The reference hard-codes all of them (src/OpticalFlow.cpp:747-751, :451, :823);
+ * papof_default_params() reproduces those values, so passing NULL == the reference. */
+typedef struct papof_params {
+    double alpha;          /* 0.012  regularisation weight                      src/OpticalFlow.cpp:747 */
+    double ratio;          /* 0.75   pyramid down-sampling ratio                :748                    */
+    int n_outer;           /* 7      outer fixed-point iterations at level 0    :749                    */
+    int n_outer_per_level; /* 1      ... plus this many per pyramid level k     :823 (nOuter+k)         */
+    int n_inner;           /* 1      inner fixed-point iterations               :750                    */
+    int n_sor;             /* 30     SOR sweeps at level 0                      :751                    */
+    int n_sor_per_level;   /* 3      ... plus this many per pyramid level k     :823 (nCG+k*3)          */
+    double omega;          /* 1.8    over-relaxation factor                     :451                    */
+    int sor_mode;          /* PAPOF_SOR_*                                                                */
+    int phase_timing;      /* 0: only Total/Construction/PostProcessing are measured (no extra syncs);
+                              1: all ten reference timers via HIP events                                */
+} papof_params;
+
+/* Index of each reference timer in timing_sec[] == sorted std::map key order, src/OpticalFlow.cpp:850-860 */
+enum {
+    PAPOF_T_ALLOCATION = 0,
+    PAPOF_T_CONSTRUCTION = 1,
+    PAPOF_T_PHASE1_GENERATE = 2,
+    PAPOF_T_PHASE2_DERIVATIVES = 3,
+    PAPOF_T_PHASE3_PSIDATA = 4,
+    PAPOF_T_PHASE4_LINEARSYSTEM = 5,
+    PAPOF_T_PHASE5_SOR = 6,
+    PAPOF_T_PHASE6_UPDATE = 7,
+    PAPOF_T_POSTPROCESSING = 8,
+    PAPOF_T_TOTAL = 9,
+    PAPOF_N_TIMERS = 10
+};
+
+typedef struct papof_handle papof_handle; /* device arena + stream; one per GPU, not thread-safe */
+
+int papof_version(void);
+void papof_default_params(papof_params* p);
+const char* papof_strerror(int code);
+const char* papof_last_error(void); /* text of the last HIP failure on this thread ("" if none) */
+const char* papof_timing_key(int index); /* "Allocation" ... "Total C++ Execution" */
+int papof_device_count(void);            /* number of visible gfx950 devices (0 if none / no driver) */
+
+int papof_create(int device, papof_handle** out);
+void papof_destroy(papof_handle* h);
+
+/* ---- THE drop-in entry point: replaces Coarse2FineFlowWrapper (src/Coarse2FineFlowWrapper.cpp:14-51).
+ * Host buffers in, host buffers out, uses a process-wide lazily created handle on device 0
+ * (or $PAPOF_DEVICE).  Internally serialised by a mutex (the reference is not re-entrant either:
+ * file-scope timers, src/OpticalFlow.cpp:39-64). */
+int papof_coarse2fine_flow(const double* im1, const double* im2, int h, int w, int c, int pyramid_levels,
+                           const papof_params* params /* NULL = reference defaults */, double* vx, double* vy,
+                           double* warpI2, double timing_sec[PAPOF_N_TIMERS] /* may be NULL */);
+
+/* Same, on an explicit handle (arena reuse across the 101 pairs of a collection, TestSuite.py:69-81). */
+int papof_flow(papof_handle* h, const double* im1, const double* im2, int height, int width, int c,
+               int pyramid_levels, const papof_params* params, double* vx, double* vy, double* warpI2,
+               double timing_sec[PAPOF_N_TIMERS]);
+
+/* Same, with every buffer already resident in this handle's device memory (HWC in, planar vx/vy and HWC
+ * warpI2 out; all fp64).  Enqueues on the handle's stream and returns after the stream has drained. */
+int papof_flow_device(papof_handle* h, const double* d_im1, const double* d_im2, int height, int width, int c,
+                      int pyramid_levels, const papof_params* params, double* d_vx, double* d_vy,
+                      double* d_warpI2, double timing_sec[PAPOF_N_TIMERS]);
+
+/* Device memory helpers for callers without a HIP binding (bench.py, ctypes users). */
+int papof_dev_alloc(papof_handle* h, size_t bytes, void** out);
+int papof_dev_free(papof_handle* h, void* p);
+int papof_dev_upload(papof_handle* h, void* dst, const void* src, size_t bytes);
+int papof_dev_download(papof_handle* h, void* dst, const void* src, size_t bytes);
+void* papof_stream(papof_handle* h); /* the hipStream_t every kernel of this handle is launched on */
+
+/* ---- stage entry points (host buffers, reference HWC layout): one per reference function on the path,
+ * used by the parity tests to check each kernel in isolation against the oracle. ---- */
+
+/* GaussianPyramid::ConstructPyramidLevels, src/GaussianPyramid.cpp:79-108.  dims[2i]=width, dims[2i+1]=
+ * height of level i; data==NULL returns only dims.  *n_elems = total doubles of all levels. */
+int papof_stage_pyramid(papof_handle* h, const double* im, int height, int width, int c, double ratio,
+                        int levels, int* dims, double* data, long* n_elems);
+/* Image::GaussianSmoothing, src/Image.h:1203-1225 (fsize <= 8). */
+int papof_stage_gaussian(papof_handle* h, const double* im, int height, int width, int c, double sigma,
+                         int fsize, double* out);
+/* Image::imresize(result, ratio) src/Image.h:751-763 ; out is int(h*ratio) x int(w*ratio). */
+int papof_stage_resize_ratio(papof_handle* h, const double* im, int height, int width, int c, double ratio,
+                             double* out);
+/* Image::imresize(w,h) src/Image.h:778-783. */
+int papof_stage_resize_wh(papof_handle* h, const double* im, int height, int width, int c, int dst_w,
+                          int dst_h, double* out);
+/* OpticalFlow::im2feature, src/OpticalFlow.cpp:911-961; returns (in *fc) 5 for c==3, 3 for c==1, else c. */
+int papof_stage_im2feature(papof_handle* h, const double* im, int height, int width, int c, double* out,
+                           int* fc);
+/* OpticalFlow::warpFL, src/OpticalFlow.cpp:154-159. */
+int papof_stage_warpFL(papof_handle* h, const double* im1, const double* im2, const double* vx,
+                       const double* vy, int height, int width, int c, double* out);
+/* OpticalFlow::getDxs, src/OpticalFlow.cpp:80-122. */
+int papof_stage_getDxs(papof_handle* h, const double* im1, const double* im2, int height, int width, int c,
+                       double* imdx, double* imdy, double* imdt);
+/* Linear system of one inner iteration with du=dv=0 (src/OpticalFlow.cpp:295-448): outputs phi, imdxy,
+ * imdx2, imdy2 and the two right-hand sides, each height*width. */
+int papof_stage_linear_system(papof_handle* h, const double* im1, const double* warp, const double* u,
+                              const double* v, int height, int width, int c, double alpha, double* phi,
+                              double* imdxy, double* imdx2, double* imdy2, double* rhs1, double* rhs2);
+/* OpticalFlow::Laplacian, src/OpticalFlow.cpp:641-690. */
+int papof_stage_laplacian(papof_handle* h, const double* in, const double* weight, int height, int width,
+                          double* out);
+/* The SOR sweeps, src/OpticalFlow.cpp:451-505, starting from du=dv=0. */
+int papof_stage_sor(papof_handle* h, const double* phi, const double* imdxy, const double* imdx2,
+                    const double* imdy2, const double* rhs1, const double* rhs2, int height, int width,
+                    double alpha, double omega, int n_sor, int sor_mode, double* du, double* dv);
+/* One pyramid level: OpticalFlow::SmoothFlowSOR, src/OpticalFlow.cpp:238-536 (n_inner must be 1).
+ * warp, u, v are in/out. */
+int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2, double* warp, double* u,
+                           double* v, int height, int width, int c, double alpha, int n_outer, int n_inner,
+                           int n_sor, double omega, int sor_mode);
+/* Image::warpImageBicubicRef + threshold, src/Image.h:2587-2701, :2031-2045 (final warp of the originals). */
+int papof_stage_bicubic_warp(papof_handle* h, const double* im1, const double* im2, const double* vx,
+                             const double* vy, int height, int width, int c, double* out);
+
+/* ---- measurement hook for bench.py: time `reps` back-to-back SOR solves of `n_sor` sweeps on synthetic
+ * coefficient planes already resident in HBM (SURVEY.md §8d micro-benchmark), with HIP events recorded
+ * on the handle's stream.  Returns average milliseconds per solve in *ms_per_solve. */
+int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_mode, int reps, unsigned seed,
+                    double* ms_per_solve);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAPOF_H */

@@ -1,0 +1,307 @@
+"""ctypes binding of the C ABI in include/papof.h (libpapof.so, HIP / gfx950).
+
+Plumbing only: numpy arrays in the reference's layout (HWC float64) go in and come out; all compute
+happens in the HIP library.  There is no CPU fallback -- if the library is missing or there is no
+usable gfx950 device every call raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpapof.so")
+
+SOR_EXACT, SOR_REDBLACK, SOR_JACOBI = 0, 1, 2
+N_TIMERS = 10
+
+_D = ctypes.POINTER(ctypes.c_double)
+_I = ctypes.POINTER(ctypes.c_int)
+c_int, c_double, c_void_p = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+
+
+class Params(ctypes.Structure):
+    """struct papof_params (include/papof.h); defaults = the reference's hard-coded constants."""
+    _fields_ = [("alpha", c_double), ("ratio", c_double), ("n_outer", c_int), ("n_outer_per_level", c_int),
+                ("n_inner", c_int), ("n_sor", c_int), ("n_sor_per_level", c_int), ("omega", c_double),
+                ("sor_mode", c_int), ("phase_timing", c_int)]
+
+
+class PapofError(RuntimeError):
+    def __init__(self, code, what, detail):
+        super().__init__("%s failed: %s (%d)%s" % (what, detail[0], code, (": " + detail[1]) if detail[1] else ""))
+        self.code = code
+
+
+_lib = None
+
+# every symbol include/papof.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "papof_version", "papof_default_params", "papof_strerror", "papof_last_error", "papof_timing_key",
+    "papof_device_count", "papof_create", "papof_destroy", "papof_coarse2fine_flow", "papof_flow",
+    "papof_flow_device", "papof_dev_alloc", "papof_dev_free", "papof_dev_upload", "papof_dev_download",
+    "papof_stream", "papof_stage_pyramid", "papof_stage_gaussian", "papof_stage_resize_ratio",
+    "papof_stage_resize_wh", "papof_stage_im2feature", "papof_stage_warpFL", "papof_stage_getDxs",
+    "papof_stage_linear_system", "papof_stage_laplacian", "papof_stage_sor", "papof_stage_smoothflow",
+    "papof_stage_bicubic_warp", "papof_bench_sor",
+]
+
+
+def load():
+    """dlopen libpapof.so (raises OSError with a build hint if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "or `make -C papteam_opticalflow_amd/csrc` (needs hipcc)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.papof_strerror.restype = ctypes.c_char_p
+    L.papof_strerror.argtypes = [c_int]
+    L.papof_last_error.restype = ctypes.c_char_p
+    L.papof_timing_key.restype = ctypes.c_char_p
+    L.papof_timing_key.argtypes = [c_int]
+    L.papof_default_params.argtypes = [ctypes.POINTER(Params)]
+    L.papof_default_params.restype = None
+    L.papof_create.argtypes = [c_int, ctypes.POINTER(c_void_p)]
+    L.papof_destroy.argtypes = [c_void_p]
+    L.papof_destroy.restype = None
+    L.papof_stream.argtypes = [c_void_p]
+    L.papof_stream.restype = c_void_p
+    PP = ctypes.POINTER(Params)
+    L.papof_coarse2fine_flow.argtypes = [_D, _D, c_int, c_int, c_int, c_int, PP, _D, _D, _D, _D]
+    L.papof_flow.argtypes = [c_void_p, _D, _D, c_int, c_int, c_int, c_int, PP, _D, _D, _D, _D]
+    L.papof_flow_device.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, PP, c_void_p, c_void_p,
+                                    c_void_p, _D]
+    L.papof_dev_alloc.argtypes = [c_void_p, ctypes.c_size_t, ctypes.POINTER(c_void_p)]
+    L.papof_dev_free.argtypes = [c_void_p, c_void_p]
+    L.papof_dev_upload.argtypes = [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]
+    L.papof_dev_download.argtypes = [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]
+    L.papof_stage_pyramid.argtypes = [c_void_p, _D, c_int, c_int, c_int, c_double, c_int, _I, _D,
+                                      ctypes.POINTER(ctypes.c_long)]
+    L.papof_stage_gaussian.argtypes = [c_void_p, _D, c_int, c_int, c_int, c_double, c_int, _D]
+    L.papof_stage_resize_ratio.argtypes = [c_void_p, _D, c_int, c_int, c_int, c_double, _D]
+    L.papof_stage_resize_wh.argtypes = [c_void_p, _D, c_int, c_int, c_int, c_int, c_int, _D]
+    L.papof_stage_im2feature.argtypes = [c_void_p, _D, c_int, c_int, c_int, _D, _I]
+    L.papof_stage_warpFL.argtypes = [c_void_p, _D, _D, _D, _D, c_int, c_int, c_int, _D]
+    L.papof_stage_getDxs.argtypes = [c_void_p, _D, _D, c_int, c_int, c_int, _D, _D, _D]
+    L.papof_stage_linear_system.argtypes = [c_void_p, _D, _D, _D, _D, c_int, c_int, c_int, c_double] + [_D] * 6
+    L.papof_stage_laplacian.argtypes = [c_void_p, _D, _D, c_int, c_int, _D]
+    L.papof_stage_sor.argtypes = [c_void_p] + [_D] * 6 + [c_int, c_int, c_double, c_double, c_int, c_int, _D, _D]
+    L.papof_stage_smoothflow.argtypes = [c_void_p, _D, _D, _D, _D, _D, c_int, c_int, c_int, c_double, c_int, c_int,
+                                         c_int, c_double, c_int]
+    L.papof_stage_bicubic_warp.argtypes = [c_void_p, _D, _D, _D, _D, c_int, c_int, c_int, _D]
+    L.papof_bench_sor.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, _D]
+    _lib = L
+    return L
+
+
+def default_params(**overrides):
+    p = Params()
+    load().papof_default_params(ctypes.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise TypeError("unknown solver parameter %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+def timing_keys():
+    L = load()
+    return [L.papof_timing_key(i).decode() for i in range(N_TIMERS)]
+
+
+def _p(a):
+    return a.ctypes.data_as(_D)
+
+
+def _c(a, ndim=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if ndim is not None and a.ndim != ndim:
+        raise ValueError("expected a %d-D array, got shape %r" % (ndim, a.shape))
+    return a
+
+
+def _chk(rc, what):
+    if rc != 0:
+        L = load()
+        raise PapofError(rc, what, (L.papof_strerror(rc).decode(), L.papof_last_error().decode()))
+
+
+def format_timing(t):
+    """The reference returns std::to_string(double) values (src/OpticalFlow.cpp:850-860): '%f' strings."""
+    return {k: "%f" % float(v) for k, v in zip(timing_keys(), t)}
+
+
+class Papof:
+    """One device handle (arena + stream).  Methods mirror the reference functions on the hot path and take /
+    return numpy arrays in the reference's HWC float64 layout."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        self.h = c_void_p()
+        _chk(self.L.papof_create(device, ctypes.byref(self.h)), "papof_create")
+
+    def close(self):
+        if self.h:
+            self.L.papof_destroy(self.h)
+            self.h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- whole call -------------------------------------------------------------------------
+    def coarse2fine_flow(self, im1, im2, levels, params=None):
+        im1, im2 = _c(im1, 3), _c(im2, 3)
+        if im1.shape != im2.shape:
+            raise ValueError("Im1 %r and Im2 %r differ in shape" % (im1.shape, im2.shape))
+        h, w, c = im1.shape
+        vx, vy, wi, t = np.zeros((h, w)), np.zeros((h, w)), np.zeros((h, w, c)), np.zeros(N_TIMERS)
+        pp = ctypes.byref(params) if params is not None else None
+        _chk(self.L.papof_flow(self.h, _p(im1), _p(im2), h, w, c, levels, pp, _p(vx), _p(vy), _p(wi), _p(t)),
+             "papof_flow")
+        return vx, vy, wi, t
+
+    def coarse2fine_flow_sched(self, im1, im2, levels, alpha, ratio, n_outer, outer_step, n_inner, n_sor, sor_step,
+                               mode=SOR_EXACT, omega=1.8):
+        p = default_params(alpha=alpha, ratio=ratio, n_outer=n_outer, n_outer_per_level=outer_step, n_inner=n_inner,
+                           n_sor=n_sor, n_sor_per_level=sor_step, sor_mode=mode, omega=omega)
+        return self.coarse2fine_flow(im1, im2, levels, p)[:3]
+
+    # ---- device-resident buffers (bench) ----------------------------------------------------------
+    def dev_alloc(self, nbytes):
+        p = c_void_p()
+        _chk(self.L.papof_dev_alloc(self.h, nbytes, ctypes.byref(p)), "papof_dev_alloc")
+        return p
+
+    def dev_free(self, p):
+        _chk(self.L.papof_dev_free(self.h, p), "papof_dev_free")
+
+    def dev_upload(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        _chk(self.L.papof_dev_upload(self.h, dptr, arr.ctypes.data_as(c_void_p), arr.nbytes), "papof_dev_upload")
+
+    def dev_download(self, arr, dptr):
+        _chk(self.L.papof_dev_download(self.h, arr.ctypes.data_as(c_void_p), dptr, arr.nbytes), "papof_dev_download")
+
+    def flow_device(self, d_im1, d_im2, h, w, c, levels, params, d_vx, d_vy, d_warp):
+        t = np.zeros(N_TIMERS)
+        pp = ctypes.byref(params) if params is not None else None
+        _chk(self.L.papof_flow_device(self.h, d_im1, d_im2, h, w, c, levels, pp, d_vx, d_vy, d_warp, _p(t)),
+             "papof_flow_device")
+        return t
+
+    def stream(self):
+        return self.L.papof_stream(self.h)
+
+    # ---- stages --------------------------------------------------------------------------------------
+    def pyramid(self, im, ratio, levels):
+        im = _c(im, 3)
+        h, w, c = im.shape
+        dims = np.zeros(2 * levels, dtype=np.int32)
+        total = ctypes.c_long(0)
+        _chk(self.L.papof_stage_pyramid(self.h, _p(im), h, w, c, ratio, levels, dims.ctypes.data_as(_I), None,
+                                        ctypes.byref(total)), "papof_stage_pyramid")
+        data = np.zeros(total.value)
+        _chk(self.L.papof_stage_pyramid(self.h, _p(im), h, w, c, ratio, levels, dims.ctypes.data_as(_I), _p(data),
+                                        ctypes.byref(total)), "papof_stage_pyramid")
+        out, off = [], 0
+        for i in range(levels):
+            lw, lh = int(dims[2 * i]), int(dims[2 * i + 1])
+            out.append(data[off:off + lw * lh * c].reshape(lh, lw, c).copy())
+            off += lw * lh * c
+        return out
+
+    def gaussian_smoothing(self, im, sigma, fsize):
+        im = _c(im, 3)
+        h, w, c = im.shape
+        out = np.zeros_like(im)
+        _chk(self.L.papof_stage_gaussian(self.h, _p(im), h, w, c, sigma, fsize, _p(out)), "papof_stage_gaussian")
+        return out
+
+    def resize_ratio(self, im, ratio):
+        im = _c(im, 3)
+        h, w, c = im.shape
+        out = np.zeros((int(float(h) * ratio), int(float(w) * ratio), c))
+        _chk(self.L.papof_stage_resize_ratio(self.h, _p(im), h, w, c, ratio, _p(out)), "papof_stage_resize_ratio")
+        return out
+
+    def resize_wh(self, im, dw, dh):
+        im = _c(im, 3)
+        h, w, c = im.shape
+        out = np.zeros((dh, dw, c))
+        _chk(self.L.papof_stage_resize_wh(self.h, _p(im), h, w, c, dw, dh, _p(out)), "papof_stage_resize_wh")
+        return out
+
+    def im2feature(self, im):
+        im = _c(im, 3)
+        h, w, c = im.shape
+        fc = c_int(0)
+        _chk(self.L.papof_stage_im2feature(self.h, None, h, w, c, None, ctypes.byref(fc)), "papof_stage_im2feature")
+        out = np.zeros((h, w, fc.value))
+        _chk(self.L.papof_stage_im2feature(self.h, _p(im), h, w, c, _p(out), ctypes.byref(fc)),
+             "papof_stage_im2feature")
+        return out
+
+    def warpFL(self, im1, im2, vx, vy):
+        im1, im2, vx, vy = _c(im1, 3), _c(im2, 3), _c(vx, 2), _c(vy, 2)
+        h, w, c = im1.shape
+        out = np.zeros_like(im1)
+        _chk(self.L.papof_stage_warpFL(self.h, _p(im1), _p(im2), _p(vx), _p(vy), h, w, c, _p(out)),
+             "papof_stage_warpFL")
+        return out
+
+    def getDxs(self, im1, im2):
+        im1, im2 = _c(im1, 3), _c(im2, 3)
+        h, w, c = im1.shape
+        dx, dy, dt = np.zeros_like(im1), np.zeros_like(im1), np.zeros_like(im1)
+        _chk(self.L.papof_stage_getDxs(self.h, _p(im1), _p(im2), h, w, c, _p(dx), _p(dy), _p(dt)),
+             "papof_stage_getDxs")
+        return dx, dy, dt
+
+    def linear_system(self, im1, warp, u, v, alpha=0.012):
+        im1, warp, u, v = _c(im1, 3), _c(warp, 3), _c(u, 2), _c(v, 2)
+        h, w, c = im1.shape
+        outs = [np.zeros((h, w)) for _ in range(6)]
+        _chk(self.L.papof_stage_linear_system(self.h, _p(im1), _p(warp), _p(u), _p(v), h, w, c, alpha,
+                                              *[_p(o) for o in outs]), "papof_stage_linear_system")
+        return outs  # phi, imdxy, imdx2, imdy2, rhs1, rhs2
+
+    def laplacian(self, x, weight):
+        x, weight = _c(x, 2), _c(weight, 2)
+        h, w = x.shape
+        out = np.zeros_like(x)
+        _chk(self.L.papof_stage_laplacian(self.h, _p(x), _p(weight), h, w, _p(out)), "papof_stage_laplacian")
+        return out
+
+    def sor(self, phi, imdxy, imdx2, imdy2, rhs1, rhs2, n_sor, alpha=0.012, omega=1.8, mode=SOR_EXACT):
+        arrs = [_c(a, 2) for a in (phi, imdxy, imdx2, imdy2, rhs1, rhs2)]
+        h, w = arrs[0].shape
+        du, dv = np.zeros((h, w)), np.zeros((h, w))
+        _chk(self.L.papof_stage_sor(self.h, *[_p(a) for a in arrs], h, w, alpha, omega, n_sor, mode, _p(du), _p(dv)),
+             "papof_stage_sor")
+        return du, dv
+
+    def smoothflow_sor(self, im1, im2, warp, u, v, alpha, n_outer, n_inner, n_sor, omega=1.8, mode=SOR_EXACT):
+        im1, im2 = _c(im1, 3), _c(im2, 3)
+        warp, u, v = _c(warp, 3).copy(), _c(u, 2).copy(), _c(v, 2).copy()
+        h, w, c = im1.shape
+        _chk(self.L.papof_stage_smoothflow(self.h, _p(im1), _p(im2), _p(warp), _p(u), _p(v), h, w, c, alpha, n_outer,
+                                           n_inner, n_sor, omega, mode), "papof_stage_smoothflow")
+        return warp, u, v
+
+    def bicubic_warp(self, im1, im2, vx, vy):
+        im1, im2, vx, vy = _c(im1, 3), _c(im2, 3), _c(vx, 2), _c(vy, 2)
+        h, w, c = im1.shape
+        out = np.zeros_like(im1)
+        _chk(self.L.papof_stage_bicubic_warp(self.h, _p(im1), _p(im2), _p(vx), _p(vy), h, w, c, _p(out)),
+             "papof_stage_bicubic_warp")
+        return out
+
+    def bench_sor(self, h, w, n_sor, mode=SOR_EXACT, reps=5, seed=2):
+        ms = c_double(0)
+        _chk(self.L.papof_bench_sor(self.h, h, w, n_sor, mode, reps, seed, ctypes.byref(ms)), "papof_bench_sor")
+        return ms.value

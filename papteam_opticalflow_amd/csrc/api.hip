@@ -1,0 +1,931 @@
+// papteam_opticalflow_amd/csrc/api.hip -- C ABI (include/papof.h) and the device-resident orchestrator
+// that replaces OpticalFlow::Coarse2FineFlow (/root/reference/Code/Serial/src/OpticalFlow.cpp:735-903)
+// and Coarse2FineFlowWrapper (src/Coarse2FineFlowWrapper.cpp:14-51).
+//
+// One call = one H2D of the two frames, every pyramid level / outer iteration / sweep on the device
+// (single stream, no host round trip in between), one D2H of vx, vy, warpI2.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <random>
+
+#include "common.h"
+
+namespace papof {
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+void set_last_error(const char* what, hipError_t e, const char* file, int line) {
+    char buf[512];
+    std::snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_last_error = buf;
+}
+const char* last_error() { return g_last_error.c_str(); }
+
+namespace {
+
+double wall() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// generous upper bound of the arena one call needs: every buffer is at most level-0 sized
+size_t arena_bytes_for(int H, int W, int C, int levels) {
+    const size_t np = (size_t)H * W;
+    const int fc = (C == 3) ? 5 : (C == 1 ? 3 : C);
+    const SkewDims sd = skew_dims(H, W);
+    size_t planes = 0;
+    planes += (size_t)2 * C * 5;           // two pyramids: sum of ratio^(2i) < 2.3 for ratio<=.75; 5 is safe to .98
+    if (levels > 8) planes += (size_t)2 * C * levels;  // (ratio .98 decays slowly: bound by level count)
+    planes += (size_t)2 * C + 2 * C;       // staging of the interleaved inputs + pyramid temporaries
+    planes += (size_t)7 * fc;              // F1, F2, warp, F1 smoothed, h-pass temp, blend, imdt
+    planes += 8;                           // u, v, resized u, v, phi + slack
+    planes += (size_t)3 * C + C;           // bicubic derivative planes + interleaved output
+    size_t bytes = planes * np * sizeof(double);
+    bytes += 10 * sd.n * sizeof(double);   // SOR operands (skewed is the larger layout)
+    bytes += (size_t)64 * 4096;            // alignment slack
+    return bytes;
+}
+
+int ensure_arena(papof_handle* h, size_t bytes) {
+    if (bytes <= h->arena.cap) return PAPOF_OK;
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    if (h->arena.base) PAPOF_HIP(hipFree(h->arena.base));
+    h->arena.base = nullptr;
+    h->arena.cap = 0;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        set_last_error("hipMalloc(arena)", e, __FILE__, __LINE__);
+        return PAPOF_ENOMEM;
+    }
+    h->arena.base = static_cast<char*>(p);
+    h->arena.cap = bytes;
+    return PAPOF_OK;
+}
+
+// ---- phase timers (HIP events on the handle's stream) ----
+struct PhaseClock {
+    papof_handle* h;
+    bool on;
+    std::vector<std::pair<int, std::pair<size_t, size_t>>> spans;  // (timer index, (event a, event b))
+    size_t open = 0;
+    int open_idx = -1;
+    int err = PAPOF_OK;
+    size_t new_event() {
+        if (h->events_used == h->events.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) {
+                err = PAPOF_EDEVICE;
+                return 0;
+            }
+            h->events.push_back(e);
+        }
+        hipEventRecord(h->events[h->events_used], h->stream);
+        return h->events_used++;
+    }
+    // close the running span (if any) and open a new one attributed to timer `idx` (-1: none)
+    void phase(int idx) {
+        if (!on) return;
+        const size_t e = new_event();
+        if (open_idx >= 0) spans.push_back({open_idx, {open, e}});
+        open = e;
+        open_idx = idx;
+    }
+    void collect(double* t) {  // after the stream has drained
+        if (!on) return;
+        for (auto& s : spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, h->events[s.second.first], h->events[s.second.second]) == hipSuccess)
+                t[s.first] += ms * 1e-3;
+        }
+    }
+};
+
+struct Level {
+    int w, h;
+    double *p1, *p2;  // planar pyramid levels of frame 1 / frame 2
+};
+
+int check_params(const papof_params& P, int levels) {
+    if (levels < 1) return PAPOF_EINVAL;
+    if (P.n_inner != 1) return PAPOF_EINVAL;  // the reference hard-codes 1 (src/OpticalFlow.cpp:750)
+    if (P.n_outer + 0 < 1 || P.n_sor < 1 || P.n_outer_per_level < 0 || P.n_sor_per_level < 0) return PAPOF_EINVAL;
+    if (P.sor_mode < PAPOF_SOR_EXACT || P.sor_mode > PAPOF_SOR_JACOBI) return PAPOF_EINVAL;
+    if (!(P.alpha > 0) || !(P.omega > 0)) return PAPOF_EINVAL;
+    return PAPOF_OK;
+}
+
+// GaussianPyramid::ConstructPyramidLevels (src/GaussianPyramid.cpp:79-108) for one frame, planar.
+// levels[i].p (selected by `which`) must be pre-allocated with the dims computed by pyramid_dims().
+struct PyrPlan {
+    int sw, sh, src_level, fsize;
+    double sigma, rate;
+};
+
+int pyramid_plan(int H, int W, double ratio, int nlev, std::vector<Level>& L, std::vector<PyrPlan>& plan) {
+    if (ratio > 0.98 || ratio < 0.4) ratio = 0.75;  // :82-83
+    const double base_sigma = 1 / ratio - 1;        // :89
+    const int n = (int)(std::log(0.25) / std::log(ratio));  // :90
+    const double n_sigma = base_sigma * n;          // :91
+    L.assign(nlev, Level{});
+    plan.assign(nlev, PyrPlan{});
+    L[0].w = W;
+    L[0].h = H;
+    for (int i = 1; i < nlev; i++) {
+        PyrPlan p;
+        if (i <= n) {  // :95-100
+            p.src_level = 0;
+            p.sigma = base_sigma * i;
+            p.fsize = (int)(p.sigma * 3);
+            p.rate = std::pow(ratio, i);
+        } else {  // :101-106
+            p.src_level = i - n;
+            p.sigma = n_sigma;
+            p.fsize = (int)(n_sigma * 3);
+            p.rate = (double)std::pow(ratio, i) * W / L[i - n].w;
+        }
+        p.sw = L[p.src_level].w;
+        p.sh = L[p.src_level].h;
+        if (p.fsize > kMaxFsize) return PAPOF_EINVAL;
+        L[i].w = (int)((double)p.sw * p.rate);  // src/Image.h:755-756
+        L[i].h = (int)((double)p.sh * p.rate);
+        if (L[i].w < 1 || L[i].h < 1) return PAPOF_EINVAL;
+        plan[i] = p;
+    }
+    return PAPOF_OK;
+}
+
+int build_pyramid(papof_handle* h, const std::vector<Level>& L, const std::vector<PyrPlan>& plan, int C, bool second,
+                  double* tmp_a, double* tmp_b) {
+    for (size_t i = 1; i < L.size(); i++) {
+        const PyrPlan& p = plan[i];
+        const double* src = second ? L[p.src_level].p2 : L[p.src_level].p1;
+        double* dst = second ? L[i].p2 : L[i].p1;
+        const Taps g = gaussian_taps(p.sigma, p.fsize);
+        PAPOF_TRY(filter_h(h, src, tmp_a, p.sh, p.sw, C, g));
+        PAPOF_TRY(filter_v(h, tmp_a, tmp_b, p.sh, p.sw, C, g));
+        PAPOF_TRY(resize(h, tmp_b, dst, p.sh, p.sw, C, L[i].h, L[i].w, p.rate, p.rate, false, 0.0));
+    }
+    return PAPOF_OK;
+}
+
+struct SolveBuffers {
+    double *im1s, *tmp, *blend, *imdt, *phi;
+    SorPlanes sp;
+};
+
+int alloc_solve_buffers(Arena& A, int H, int W, int fc, int mode, SolveBuffers& B) {
+    const size_t np = (size_t)H * W;
+    B.im1s = A.f64(np * fc);
+    B.tmp = A.f64(np * fc);
+    B.blend = A.f64(np * fc);
+    B.imdt = A.f64(np * fc);
+    B.phi = A.f64(np);
+    const bool skew = mode == PAPOF_SOR_EXACT;
+    const size_t n = skew ? skew_dims(H, W).n + kLanes : np;
+    B.sp.skew = skew;
+    B.sp.phi = A.f64(n);
+    B.sp.xy = A.f64(n);
+    B.sp.a1 = A.f64(n);
+    B.sp.a2 = A.f64(n);
+    B.sp.b1 = A.f64(n);
+    B.sp.b2 = A.f64(n);
+    B.sp.du = A.f64(n);
+    B.sp.dv = A.f64(n);
+    B.sp.du2 = B.sp.dv2 = nullptr;
+    if (mode == PAPOF_SOR_JACOBI) {
+        B.sp.du2 = A.f64(n);
+        B.sp.dv2 = A.f64(n);
+    }
+    return A.overflow ? PAPOF_ENOMEM : PAPOF_OK;
+}
+
+// OpticalFlow::SmoothFlowSOR (src/OpticalFlow.cpp:238-536) for one level, everything on the device.
+// genInImageMask (:278) and estLaplacianNoise (:530) do not influence the results (the mask
+// is never read; the noise estimate only feeds a `< 1e-20` guard) and are not executed.
+int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* warp, double* u, double* v, int H,
+                int W, int fc, double alpha, int n_outer, int n_sor, double omega, int mode, SolveBuffers& B,
+                PhaseClock& clk) {
+    const Taps g = smooth5_taps();
+    clk.phase(PAPOF_T_PHASE1_GENERATE);
+    PAPOF_TRY(filter_h(h, f1, B.tmp, H, W, fc, g));  // smoothed frame 1: constant within the level
+    PAPOF_TRY(filter_v(h, B.tmp, B.im1s, H, W, fc, g));
+    for (int count = 0; count < n_outer; count++) {
+        clk.phase(PAPOF_T_PHASE1_GENERATE);
+        PAPOF_TRY(filter_h(h, warp, B.tmp, H, W, fc, g));
+        PAPOF_TRY(smooth_v_blend(h, B.tmp, B.im1s, B.blend, B.imdt, H, W, fc));
+        clk.phase(PAPOF_T_PHASE2_DERIVATIVES);
+        PAPOF_TRY(compute_phi(h, u, v, B.phi, H, W));
+        clk.phase(PAPOF_T_PHASE4_LINEARSYSTEM);  // psi (Phase3) is fused into the assembly kernel
+        PAPOF_TRY(assemble_system(h, B.blend, B.imdt, B.phi, u, v, H, W, fc, alpha, omega, B.sp, nullptr, nullptr));
+        clk.phase(PAPOF_T_PHASE5_SOR);
+        PAPOF_TRY(sor_solve(h, B.sp, H, W, alpha, omega, n_sor, mode));
+        clk.phase(PAPOF_T_PHASE6_UPDATE);
+        PAPOF_TRY(update_and_warp(h, B.sp, u, v, f1, f2, warp, H, W, fc));
+    }
+    clk.phase(-1);
+    return PAPOF_OK;
+}
+
+int feature_channels(int C) { return C == 3 ? 5 : (C == 1 ? 3 : C); }
+
+}  // namespace
+
+// The whole call on device-resident buffers.
+int flow_device(papof_handle* h, const double* d_im1, const double* d_im2, int H, int W, int C, int levels,
+                const papof_params& P, double* d_vx, double* d_vy, double* d_warp, double* timing) {
+    PAPOF_TRY(check_params(P, levels));
+    double ratio = P.ratio;
+    if (ratio > 0.98 || ratio < 0.4) ratio = 0.75;
+    std::vector<Level> L;
+    std::vector<PyrPlan> plan;
+    PAPOF_TRY(pyramid_plan(H, W, P.ratio, levels, L, plan));
+    PAPOF_TRY(ensure_arena(h, arena_bytes_for(H, W, C, levels)));
+    Arena& A = h->arena;
+    A.off = 0;
+    A.overflow = false;
+    h->events_used = 0;
+    const size_t np0 = (size_t)H * W;
+    const int fc = feature_channels(C);
+    double tm[PAPOF_N_TIMERS];
+    std::memset(tm, 0, sizeof tm);
+    PhaseClock clk{h, P.phase_timing != 0};
+    PhaseClock total{h, true};
+
+    total.phase(PAPOF_T_TOTAL);
+    clk.phase(PAPOF_T_CONSTRUCTION);
+    for (int i = 0; i < levels; i++) {
+        L[i].p1 = A.f64((size_t)L[i].w * L[i].h * C);
+        L[i].p2 = A.f64((size_t)L[i].w * L[i].h * C);
+    }
+    double* tmp_a = A.f64(np0 * C);
+    double* tmp_b = A.f64(np0 * C);
+    if (A.overflow) return PAPOF_ENOMEM;
+    PAPOF_TRY(hwc_to_planar(h, d_im1, L[0].p1, H, W, C));
+    PAPOF_TRY(hwc_to_planar(h, d_im2, L[0].p2, H, W, C));
+    PAPOF_TRY(build_pyramid(h, L, plan, C, false, tmp_a, tmp_b));
+    PAPOF_TRY(build_pyramid(h, L, plan, C, true, tmp_a, tmp_b));
+
+    double* f1 = A.f64(np0 * fc);
+    double* f2 = A.f64(np0 * fc);
+    double* warp = A.f64(np0 * fc);
+    double* u = A.f64(np0);
+    double* v = A.f64(np0);
+    double* u2 = A.f64(np0);
+    double* v2 = A.f64(np0);
+    SolveBuffers B;
+    PAPOF_TRY(alloc_solve_buffers(A, H, W, fc, P.sor_mode, B));
+    if (A.overflow) return PAPOF_ENOMEM;
+
+    int pw = 0, ph = 0;
+    for (int k = levels - 1; k >= 0; k--) {
+        clk.phase(PAPOF_T_ALLOCATION);
+        const int lw = L[k].w, lh = L[k].h;
+        const size_t np = (size_t)lw * lh;
+        PAPOF_TRY(im2feature(h, L[k].p1, f1, lh, lw, C));  // src/OpticalFlow.cpp:797-798
+        PAPOF_TRY(im2feature(h, L[k].p2, f2, lh, lw, C));
+        if (k == levels - 1) {  // :801-806
+            PAPOF_HIP(hipMemsetAsync(u, 0, np * sizeof(double), h->stream));
+            PAPOF_HIP(hipMemsetAsync(v, 0, np * sizeof(double), h->stream));
+            PAPOF_HIP(hipMemcpyAsync(warp, f2, np * fc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        } else {  // :809-814
+            const double xr = (double)lw / pw, yr = (double)lh / ph, inv = 1 / ratio;
+            PAPOF_TRY(resize(h, u, u2, ph, pw, 1, lh, lw, xr, yr, true, inv));
+            PAPOF_TRY(resize(h, v, v2, ph, pw, 1, lh, lw, xr, yr, true, inv));
+            std::swap(u, u2);
+            std::swap(v, v2);
+            PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc));
+        }
+        PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, lh, lw, fc, P.alpha, P.n_outer + k * P.n_outer_per_level,
+                              P.n_sor + k * P.n_sor_per_level, P.omega, P.sor_mode, B, clk));
+        pw = lw;
+        ph = lh;
+    }
+
+    clk.phase(PAPOF_T_POSTPROCESSING);  // src/OpticalFlow.cpp:841-842
+    {
+        double* gx = A.f64(np0 * C);
+        double* gy = A.f64(np0 * C);
+        double* gxy = A.f64(np0 * C);
+        if (A.overflow) return PAPOF_ENOMEM;
+        const Taps c3 = central3_taps();
+        PAPOF_TRY(filter_h(h, L[0].p2, gx, H, W, C, c3));
+        PAPOF_TRY(filter_v(h, L[0].p2, gy, H, W, C, c3));
+        PAPOF_TRY(filter_v(h, gx, gxy, H, W, C, c3));
+        PAPOF_TRY(bicubic_warp(h, L[0].p1, L[0].p2, gx, gy, gxy, u, v, d_warp, H, W, C));
+        PAPOF_HIP(hipMemcpyAsync(d_vx, u, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        PAPOF_HIP(hipMemcpyAsync(d_vy, v, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+    clk.phase(-1);
+    total.phase(-1);
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    if (P.sor_mode == PAPOF_SOR_EXACT) PAPOF_TRY(sor_check(h));
+    if (clk.err != PAPOF_OK || total.err != PAPOF_OK) return PAPOF_EDEVICE;
+    clk.collect(tm);
+    total.collect(tm);
+    if (timing) std::memcpy(timing, tm, sizeof tm);
+    return PAPOF_OK;
+}
+
+}  // namespace papof
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using namespace papof;
+
+extern "C" {
+
+int papof_version(void) { return PAPOF_VERSION; }
+
+void papof_default_params(papof_params* p) {
+    if (!p) return;
+    p->alpha = 0.012;
+    p->ratio = 0.75;
+    p->n_outer = 7;
+    p->n_outer_per_level = 1;
+    p->n_inner = 1;
+    p->n_sor = 30;
+    p->n_sor_per_level = 3;
+    p->omega = 1.8;
+    p->sor_mode = PAPOF_SOR_EXACT;
+    p->phase_timing = 0;
+}
+
+const char* papof_strerror(int code) {
+    switch (code) {
+        case PAPOF_OK: return "ok";
+        case PAPOF_EINVAL: return "invalid argument";
+        case PAPOF_ENODEVICE: return "no usable gfx950 device";
+        case PAPOF_ENOMEM: return "out of memory";
+        case PAPOF_EDEVICE: return "HIP runtime error";
+        case PAPOF_ETIMEOUT: return "device-side wait timed out";
+    }
+    return "unknown error";
+}
+
+const char* papof_last_error(void) { return last_error(); }
+
+const char* papof_timing_key(int i) {
+    static const char* keys[PAPOF_N_TIMERS] = {"Allocation",         "Construction",        "Phase1_Generate",
+                                               "Phase2_Derivatives", "Phase3_PsiData",      "Phase4_LinearSystem",
+                                               "Phase5_SOR",         "Phase6_Update",       "PostProcessing",
+                                               "Total C++ Execution"};
+    return (i >= 0 && i < PAPOF_N_TIMERS) ? keys[i] : "";
+}
+
+int papof_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int papof_create(int device, papof_handle** out) {
+    if (!out) return PAPOF_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        set_last_error("hipGetDeviceCount", e, __FILE__, __LINE__);
+        return PAPOF_ENODEVICE;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+        set_last_error("hipGetDeviceProperties", e, __FILE__, __LINE__);
+        return PAPOF_ENODEVICE;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {  // the code object is gfx950-only by design
+        g_last_error = std::string("device is ") + prop.gcnArchName + ", libpapof is built for gfx950 only";
+        return PAPOF_ENODEVICE;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        set_last_error("hipSetDevice", e, __FILE__, __LINE__);
+        return PAPOF_ENODEVICE;
+    }
+    papof_handle* h = new papof_handle();
+    h->device = device;
+    h->cu_count = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+        set_last_error("hipStreamCreate", e, __FILE__, __LINE__);
+        delete h;
+        return PAPOF_ENODEVICE;
+    }
+    *out = h;
+    return PAPOF_OK;
+}
+
+void papof_destroy(papof_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    for (hipEvent_t e : h->events) hipEventDestroy(e);
+    if (h->arena.base) hipFree(h->arena.base);
+    if (h->sync_words) hipFree(h->sync_words);
+    hipStreamDestroy(h->stream);
+    delete h;
+}
+
+void* papof_stream(papof_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int papof_dev_alloc(papof_handle* h, size_t bytes, void** out) {
+    if (!h || !out) return PAPOF_EINVAL;
+    PAPOF_HIP(hipSetDevice(h->device));
+    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        set_last_error("hipMalloc", e, __FILE__, __LINE__);
+        return PAPOF_ENOMEM;
+    }
+    return PAPOF_OK;
+}
+
+int papof_dev_free(papof_handle* h, void* p) {
+    if (!h) return PAPOF_EINVAL;
+    PAPOF_HIP(hipSetDevice(h->device));
+    PAPOF_HIP(hipFree(p));
+    return PAPOF_OK;
+}
+
+int papof_dev_upload(papof_handle* h, void* dst, const void* src, size_t bytes) {
+    if (!h || !dst || !src) return PAPOF_EINVAL;
+    PAPOF_HIP(hipSetDevice(h->device));
+    PAPOF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    return PAPOF_OK;
+}
+
+int papof_dev_download(papof_handle* h, void* dst, const void* src, size_t bytes) {
+    if (!h || !dst || !src) return PAPOF_EINVAL;
+    PAPOF_HIP(hipSetDevice(h->device));
+    PAPOF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    return PAPOF_OK;
+}
+
+int papof_flow_device(papof_handle* h, const double* d_im1, const double* d_im2, int height, int width, int c,
+                      int pyramid_levels, const papof_params* params, double* d_vx, double* d_vy, double* d_warpI2,
+                      double timing_sec[PAPOF_N_TIMERS]) {
+    if (!h || !d_im1 || !d_im2 || !d_vx || !d_vy || !d_warpI2 || height < 1 || width < 1 || c < 1)
+        return PAPOF_EINVAL;
+    papof_params P;
+    if (params)
+        P = *params;
+    else
+        papof_default_params(&P);
+    PAPOF_HIP(hipSetDevice(h->device));
+    return flow_device(h, d_im1, d_im2, height, width, c, pyramid_levels, P, d_vx, d_vy, d_warpI2, timing_sec);
+}
+
+int papof_flow(papof_handle* h, const double* im1, const double* im2, int height, int width, int c,
+               int pyramid_levels, const papof_params* params, double* vx, double* vy, double* warpI2,
+               double timing_sec[PAPOF_N_TIMERS]) {
+    if (!h || !im1 || !im2 || !vx || !vy || !warpI2 || height < 1 || width < 1 || c < 1 || pyramid_levels < 1)
+        return PAPOF_EINVAL;
+    const double t0 = wall();
+    PAPOF_HIP(hipSetDevice(h->device));
+    const size_t np = (size_t)height * width, nb_img = np * c * sizeof(double), nb_flow = np * sizeof(double);
+    // staging block for the interleaved frames and results (separate from the arena, which flow_device resets)
+    double* stage = nullptr;
+    hipError_t e = hipMalloc((void**)&stage, 3 * nb_img + 2 * nb_flow);
+    if (e != hipSuccess) {
+        set_last_error("hipMalloc(stage)", e, __FILE__, __LINE__);
+        return PAPOF_ENOMEM;
+    }
+    double* d1 = stage;
+    double* d2 = d1 + np * c;
+    double* dw = d2 + np * c;
+    double* dx = dw + np * c;
+    double* dy = dx + np;
+    int rc = PAPOF_OK;
+    double tm[PAPOF_N_TIMERS];
+    std::memset(tm, 0, sizeof tm);
+    do {
+        if (hipMemcpyAsync(d1, im1, nb_img, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(d2, im2, nb_img, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+            rc = PAPOF_EDEVICE;
+            break;
+        }
+        rc = papof_flow_device(h, d1, d2, height, width, c, pyramid_levels, params, dx, dy, dw, tm);
+        if (rc != PAPOF_OK) break;
+        if (hipMemcpyAsync(vx, dx, nb_flow, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipMemcpyAsync(vy, dy, nb_flow, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipMemcpyAsync(warpI2, dw, nb_img, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) {
+            rc = PAPOF_EDEVICE;
+            break;
+        }
+    } while (0);
+    hipFree(stage);
+    if (rc == PAPOF_OK && timing_sec) {
+        tm[PAPOF_T_TOTAL] = wall() - t0;  // the caller-visible total includes both PCIe transfers
+        std::memcpy(timing_sec, tm, sizeof tm);
+    }
+    return rc;
+}
+
+static std::mutex g_default_mu;
+static papof_handle* g_default = nullptr;
+
+int papof_coarse2fine_flow(const double* im1, const double* im2, int h, int w, int c, int pyramid_levels,
+                           const papof_params* params, double* vx, double* vy, double* warpI2,
+                           double timing_sec[PAPOF_N_TIMERS]) {
+    std::lock_guard<std::mutex> lock(g_default_mu);
+    if (!g_default) {
+        int dev = 0;
+        if (const char* s = std::getenv("PAPOF_DEVICE")) dev = std::atoi(s);
+        PAPOF_TRY(papof_create(dev, &g_default));
+    }
+    return papof_flow(g_default, im1, im2, h, w, c, pyramid_levels, params, vx, vy, warpI2, timing_sec);
+}
+
+// -------------------------------------------------------------------------------------------------
+// stage entry points (host buffers, reference HWC layout)
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+struct Scope {  // arena scope + device selection for one stage call
+    papof_handle* h;
+    int rc;
+    Scope(papof_handle* hh, size_t bytes) : h(hh), rc(PAPOF_OK) {
+        if (!h) {
+            rc = PAPOF_EINVAL;
+            return;
+        }
+        if (hipSetDevice(h->device) != hipSuccess) {
+            rc = PAPOF_EDEVICE;
+            return;
+        }
+        rc = ensure_arena(h, bytes + (1 << 20));
+        h->arena.off = 0;
+        h->arena.overflow = false;
+    }
+    // upload an HWC host image as planar device planes
+    double* up_planar(const double* host, int H, int W, int C) {
+        const size_t n = (size_t)H * W * C;
+        double* raw = h->arena.f64(n);
+        double* pl = h->arena.f64(n);
+        if (!raw || !pl) {
+            rc = PAPOF_ENOMEM;
+            return nullptr;
+        }
+        if (hipMemcpyAsync(raw, host, n * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+            rc = PAPOF_EDEVICE;
+            return nullptr;
+        }
+        if (C == 1) return raw;
+        int r = hwc_to_planar(h, raw, pl, H, W, C);
+        if (r != PAPOF_OK) rc = r;
+        return pl;
+    }
+    double* dev(size_t n) {
+        double* p = h->arena.f64(n);
+        if (!p) rc = PAPOF_ENOMEM;
+        return p;
+    }
+    // download planar device planes into an HWC host image
+    int down_planar(const double* planar, double* host, int H, int W, int C) {
+        const size_t n = (size_t)H * W * C;
+        const double* src = planar;
+        if (C != 1) {
+            double* raw = h->arena.f64(n);
+            if (!raw) return PAPOF_ENOMEM;
+            PAPOF_TRY(planar_to_hwc(h, planar, raw, H, W, C));
+            src = raw;
+        }
+        PAPOF_HIP(hipMemcpyAsync(host, src, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        PAPOF_HIP(hipStreamSynchronize(h->stream));
+        return PAPOF_OK;
+    }
+};
+
+size_t img_bytes(int H, int W, int C, int copies) { return (size_t)H * W * C * sizeof(double) * copies; }
+
+}  // namespace
+
+int papof_stage_pyramid(papof_handle* h, const double* im, int height, int width, int c, double ratio, int levels,
+                        int* dims, double* data, long* n_elems) {
+    if (!h || !dims || height < 1 || width < 1 || c < 1 || levels < 1) return PAPOF_EINVAL;
+    std::vector<Level> L;
+    std::vector<PyrPlan> plan;
+    PAPOF_TRY(pyramid_plan(height, width, ratio, levels, L, plan));
+    long total = 0;
+    for (int i = 0; i < levels; i++) {
+        dims[2 * i] = L[i].w;
+        dims[2 * i + 1] = L[i].h;
+        total += (long)L[i].w * L[i].h * c;
+    }
+    if (n_elems) *n_elems = total;
+    if (!data) return PAPOF_OK;
+    if (!im) return PAPOF_EINVAL;
+    Scope S(h, img_bytes(height, width, c, 6) + (size_t)total * sizeof(double) * 2);
+    PAPOF_TRY(S.rc);
+    L[0].p1 = S.up_planar(im, height, width, c);
+    for (int i = 1; i < levels; i++) L[i].p1 = S.dev((size_t)L[i].w * L[i].h * c);
+    double* ta = S.dev((size_t)height * width * c);
+    double* tb = S.dev((size_t)height * width * c);
+    PAPOF_TRY(S.rc);
+    PAPOF_TRY(build_pyramid(h, L, plan, c, false, ta, tb));
+    long off = 0;
+    for (int i = 0; i < levels; i++) {
+        PAPOF_TRY(S.down_planar(L[i].p1, data + off, L[i].h, L[i].w, c));
+        off += (long)L[i].w * L[i].h * c;
+    }
+    return PAPOF_OK;
+}
+
+int papof_stage_gaussian(papof_handle* h, const double* im, int height, int width, int c, double sigma, int fsize,
+                         double* out) {
+    if (!h || !im || !out || height < 1 || width < 1 || c < 1 || fsize < 0 || fsize > kMaxFsize)
+        return PAPOF_EINVAL;
+    Scope S(h, img_bytes(height, width, c, 6));
+    PAPOF_TRY(S.rc);
+    double* src = S.up_planar(im, height, width, c);
+    double* ta = S.dev((size_t)height * width * c);
+    double* tb = S.dev((size_t)height * width * c);
+    PAPOF_TRY(S.rc);
+    const Taps g = gaussian_taps(sigma, fsize);
+    PAPOF_TRY(filter_h(h, src, ta, height, width, c, g));
+    PAPOF_TRY(filter_v(h, ta, tb, height, width, c, g));
+    return S.down_planar(tb, out, height, width, c);
+}
+
+int papof_stage_resize_ratio(papof_handle* h, const double* im, int height, int width, int c, double ratio,
+                             double* out) {
+    if (!h || !im || !out || height < 1 || width < 1 || c < 1 || !(ratio > 0)) return PAPOF_EINVAL;
+    const int dw = (int)((double)width * ratio), dh = (int)((double)height * ratio);
+    if (dw < 1 || dh < 1) return PAPOF_EINVAL;
+    Scope S(h, img_bytes(height, width, c, 3) + img_bytes(dh, dw, c, 3));
+    PAPOF_TRY(S.rc);
+    double* src = S.up_planar(im, height, width, c);
+    double* dst = S.dev((size_t)dw * dh * c);
+    PAPOF_TRY(S.rc);
+    PAPOF_TRY(resize(h, src, dst, height, width, c, dh, dw, ratio, ratio, false, 0.0));
+    return S.down_planar(dst, out, dh, dw, c);
+}
+
+int papof_stage_resize_wh(papof_handle* h, const double* im, int height, int width, int c, int dst_w, int dst_h,
+                          double* out) {
+    if (!h || !im || !out || height < 1 || width < 1 || c < 1 || dst_w < 1 || dst_h < 1) return PAPOF_EINVAL;
+    Scope S(h, img_bytes(height, width, c, 3) + img_bytes(dst_h, dst_w, c, 3));
+    PAPOF_TRY(S.rc);
+    double* src = S.up_planar(im, height, width, c);
+    double* dst = S.dev((size_t)dst_w * dst_h * c);
+    PAPOF_TRY(S.rc);
+    PAPOF_TRY(resize(h, src, dst, height, width, c, dst_h, dst_w, (double)dst_w / width, (double)dst_h / height,
+                     false, 0.0));
+    return S.down_planar(dst, out, dst_h, dst_w, c);
+}
+
+int papof_stage_im2feature(papof_handle* h, const double* im, int height, int width, int c, double* out, int* fc) {
+    if (!h || height < 1 || width < 1 || c < 1) return PAPOF_EINVAL;
+    const int f = feature_channels(c);
+    if (fc) *fc = f;
+    if (!out) return PAPOF_OK;
+    if (!im) return PAPOF_EINVAL;
+    Scope S(h, img_bytes(height, width, c, 3) + img_bytes(height, width, f, 3));
+    PAPOF_TRY(S.rc);
+    double* src = S.up_planar(im, height, width, c);
+    double* dst = S.dev((size_t)height * width * f);
+    PAPOF_TRY(S.rc);
+    PAPOF_TRY(im2feature(h, src, dst, height, width, c));
+    return S.down_planar(dst, out, height, width, f);
+}
+
+int papof_stage_warpFL(papof_handle* h, const double* im1, const double* im2, const double* vx, const double* vy,
+                       int height, int width, int c, double* out) {
+    if (!h || !im1 || !im2 || !vx || !vy || !out || height < 1 || width < 1 || c < 1) return PAPOF_EINVAL;
+    Scope S(h, img_bytes(height, width, c, 8) + img_bytes(height, width, 1, 4));
+    PAPOF_TRY(S.rc);
+    double* a = S.up_planar(im1, height, width, c);
+    double* b = S.up_planar(im2, height, width, c);
+    double* fx = S.up_planar(vx, height, width, 1);
+    double* fy = S.up_planar(vy, height, width, 1);
+    double* dst = S.dev((size_t)height * width * c);
+    PAPOF_TRY(S.rc);
+    PAPOF_TRY(warp_bilinear(h, a, b, fx, fy, dst, height, width, c));
+    return S.down_planar(dst, out, height, width, c);
+}
+
+int papof_stage_getDxs(papof_handle* h, const double* im1, const double* im2, int height, int width, int c,
+                       double* imdx, double* imdy, double* imdt) {
+    if (!h || !im1 || !im2 || !imdx || !imdy || !imdt || height < 1 || width < 1 || c < 1) return PAPOF_EINVAL;
+    Scope S(h, img_bytes(height, width, c, 14));
+    PAPOF_TRY(S.rc);
+    const size_t n = (size_t)height * width * c;
+    double* a = S.up_planar(im1, height, width, c);
+    double* b = S.up_planar(im2, height, width, c);
+    double *tmp = S.dev(n), *im1s = S.dev(n), *blend = S.dev(n), *dt = S.dev(n), *gx = S.dev(n), *gy = S.dev(n);
+    PAPOF_TRY(S.rc);
+    const Taps g = smooth5_taps(), d = deriv5_taps();
+    PAPOF_TRY(filter_h(h, a, tmp, height, width, c, g));
+    PAPOF_TRY(filter_v(h, tmp, im1s, height, width, c, g));
+    PAPOF_TRY(filter_h(h, b, tmp, height, width, c, g));
+    PAPOF_TRY(smooth_v_blend(h, tmp, im1s, blend, dt, height, width, c));
+    PAPOF_TRY(filter_h(h, blend, gx, height, width, c, d));
+    PAPOF_TRY(filter_v(h, blend, gy, height, width, c, d));
+    PAPOF_TRY(S.down_planar(gx, imdx, height, width, c));
+    PAPOF_TRY(S.down_planar(gy, imdy, height, width, c));
+    return S.down_planar(dt, imdt, height, width, c);
+}
+
+int papof_stage_linear_system(papof_handle* h, const double* im1, const double* warp, const double* u,
+                              const double* v, int height, int width, int c, double alpha, double* phi,
+                              double* imdxy, double* imdx2, double* imdy2, double* rhs1, double* rhs2) {
+    if (!h || !im1 || !warp || !u || !v || !phi || !imdxy || !imdx2 || !imdy2 || !rhs1 || !rhs2 || height < 1 ||
+        width < 1 || c < 1)
+        return PAPOF_EINVAL;
+    Scope S(h, img_bytes(height, width, c, 10) + img_bytes(height, width, 1, 20));
+    PAPOF_TRY(S.rc);
+    const size_t np = (size_t)height * width, n = np * c;
+    double* a = S.up_planar(im1, height, width, c);
+    double* b = S.up_planar(warp, height, width, c);
+    double* du = S.up_planar(u, height, width, 1);
+    double* dv = S.up_planar(v, height, width, 1);
+    double *tmp = S.dev(n), *im1s = S.dev(n), *blend = S.dev(n), *dt = S.dev(n), *dphi = S.dev(np);
+    SorPlanes sp{};
+    sp.skew = false;
+    sp.phi = S.dev(np);
+    sp.xy = S.dev(np);
+    sp.a1 = S.dev(np);
+    sp.a2 = S.dev(np);
+    sp.b1 = S.dev(np);
+    sp.b2 = S.dev(np);
+    double *x2 = S.dev(np), *y2 = S.dev(np);
+    PAPOF_TRY(S.rc);
+    const Taps g = smooth5_taps();
+    PAPOF_TRY(filter_h(h, a, tmp, height, width, c, g));
+    PAPOF_TRY(filter_v(h, tmp, im1s, height, width, c, g));
+    PAPOF_TRY(filter_h(h, b, tmp, height, width, c, g));
+    PAPOF_TRY(smooth_v_blend(h, tmp, im1s, blend, dt, height, width, c));
+    PAPOF_TRY(compute_phi(h, du, dv, dphi, height, width));
+    PAPOF_TRY(assemble_system(h, blend, dt, dphi, du, dv, height, width, c, alpha, 1.8, sp, x2, y2));
+    PAPOF_TRY(S.down_planar(dphi, phi, height, width, 1));
+    PAPOF_TRY(S.down_planar(sp.xy, imdxy, height, width, 1));
+    PAPOF_TRY(S.down_planar(x2, imdx2, height, width, 1));
+    PAPOF_TRY(S.down_planar(y2, imdy2, height, width, 1));
+    PAPOF_TRY(S.down_planar(sp.b1, rhs1, height, width, 1));
+    return S.down_planar(sp.b2, rhs2, height, width, 1);
+}
+
+int papof_stage_laplacian(papof_handle* h, const double* in, const double* weight, int height, int width,
+                          double* out) {
+    if (!h || !in || !weight || !out || height < 1 || width < 1) return PAPOF_EINVAL;
+    Scope S(h, img_bytes(height, width, 1, 6));
+    PAPOF_TRY(S.rc);
+    double* a = S.up_planar(in, height, width, 1);
+    double* w = S.up_planar(weight, height, width, 1);
+    double* o = S.dev((size_t)height * width);
+    PAPOF_TRY(S.rc);
+    PAPOF_TRY(laplacian(h, a, w, o, height, width));
+    return S.down_planar(o, out, height, width, 1);
+}
+
+namespace {
+int alloc_sor_planes(Scope& S, int H, int W, int mode, SorPlanes& sp) {
+    const bool skew = mode == PAPOF_SOR_EXACT;
+    const size_t n = skew ? skew_dims(H, W).n + kLanes : (size_t)H * W;
+    sp.skew = skew;
+    sp.phi = S.dev(n);
+    sp.xy = S.dev(n);
+    sp.a1 = S.dev(n);
+    sp.a2 = S.dev(n);
+    sp.b1 = S.dev(n);
+    sp.b2 = S.dev(n);
+    sp.du = S.dev(n);
+    sp.dv = S.dev(n);
+    sp.du2 = sp.dv2 = nullptr;
+    if (mode == PAPOF_SOR_JACOBI) {
+        sp.du2 = S.dev(n);
+        sp.dv2 = S.dev(n);
+    }
+    return S.rc;
+}
+}  // namespace
+
+int papof_stage_sor(papof_handle* h, const double* phi, const double* imdxy, const double* imdx2,
+                    const double* imdy2, const double* rhs1, const double* rhs2, int height, int width,
+                    double alpha, double omega, int n_sor, int sor_mode, double* du, double* dv) {
+    if (!h || !phi || !imdxy || !imdx2 || !imdy2 || !rhs1 || !rhs2 || !du || !dv || height < 1 || width < 1 ||
+        n_sor < 1 || sor_mode < PAPOF_SOR_EXACT || sor_mode > PAPOF_SOR_JACOBI)
+        return PAPOF_EINVAL;
+    const size_t np = (size_t)height * width;
+    Scope S(h, img_bytes(height, width, 1, 16) + 12 * (skew_dims(height, width).n + 64) * sizeof(double));
+    PAPOF_TRY(S.rc);
+    double* p = S.up_planar(phi, height, width, 1);
+    double* xy = S.up_planar(imdxy, height, width, 1);
+    double* x2 = S.up_planar(imdx2, height, width, 1);
+    double* y2 = S.up_planar(imdy2, height, width, 1);
+    double* r1 = S.up_planar(rhs1, height, width, 1);
+    double* r2 = S.up_planar(rhs2, height, width, 1);
+    double *ou = S.dev(np), *ov = S.dev(np);
+    SorPlanes sp{};
+    PAPOF_TRY(alloc_sor_planes(S, height, width, sor_mode, sp));
+    PAPOF_TRY(sor_prep(h, p, xy, x2, y2, r1, r2, height, width, alpha, omega, sp));
+    PAPOF_TRY(sor_solve(h, sp, height, width, alpha, omega, n_sor, sor_mode));
+    PAPOF_TRY(sor_unpack(h, sp, ou, ov, height, width));
+    PAPOF_TRY(S.down_planar(ou, du, height, width, 1));
+    PAPOF_TRY(S.down_planar(ov, dv, height, width, 1));
+    if (sor_mode == PAPOF_SOR_EXACT) PAPOF_TRY(sor_check(h));
+    return PAPOF_OK;
+}
+
+int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2, double* warp, double* u,
+                           double* v, int height, int width, int c, double alpha, int n_outer, int n_inner,
+                           int n_sor, double omega, int sor_mode) {
+    if (!h || !im1 || !im2 || !warp || !u || !v || height < 1 || width < 1 || c < 1 || n_outer < 1 || n_sor < 1 ||
+        sor_mode < PAPOF_SOR_EXACT || sor_mode > PAPOF_SOR_JACOBI)
+        return PAPOF_EINVAL;
+    if (n_inner != 1) return PAPOF_EINVAL;
+    Scope S(h, img_bytes(height, width, c, 12) + img_bytes(height, width, 1, 8) +
+                   12 * (skew_dims(height, width).n + 64) * sizeof(double));
+    PAPOF_TRY(S.rc);
+    double* f1 = S.up_planar(im1, height, width, c);
+    double* f2 = S.up_planar(im2, height, width, c);
+    double* w = S.up_planar(warp, height, width, c);
+    double* du = S.up_planar(u, height, width, 1);
+    double* dv = S.up_planar(v, height, width, 1);
+    PAPOF_TRY(S.rc);
+    SolveBuffers B;
+    PAPOF_TRY(alloc_solve_buffers(h->arena, height, width, c, sor_mode, B));
+    PhaseClock clk{h, false};
+    PAPOF_TRY(smooth_flow(h, f1, f2, w, du, dv, height, width, c, alpha, n_outer, n_sor, omega, sor_mode, B, clk));
+    PAPOF_TRY(S.down_planar(w, warp, height, width, c));
+    PAPOF_TRY(S.down_planar(du, u, height, width, 1));
+    PAPOF_TRY(S.down_planar(dv, v, height, width, 1));
+    if (sor_mode == PAPOF_SOR_EXACT) PAPOF_TRY(sor_check(h));
+    return PAPOF_OK;
+}
+
+int papof_stage_bicubic_warp(papof_handle* h, const double* im1, const double* im2, const double* vx,
+                             const double* vy, int height, int width, int c, double* out) {
+    if (!h || !im1 || !im2 || !vx || !vy || !out || height < 1 || width < 1 || c < 1) return PAPOF_EINVAL;
+    Scope S(h, img_bytes(height, width, c, 10) + img_bytes(height, width, 1, 4));
+    PAPOF_TRY(S.rc);
+    const size_t n = (size_t)height * width * c;
+    double* a = S.up_planar(im1, height, width, c);
+    double* b = S.up_planar(im2, height, width, c);
+    double* fx = S.up_planar(vx, height, width, 1);
+    double* fy = S.up_planar(vy, height, width, 1);
+    double *gx = S.dev(n), *gy = S.dev(n), *gxy = S.dev(n), *o = S.dev(n);
+    PAPOF_TRY(S.rc);
+    const Taps c3 = central3_taps();
+    PAPOF_TRY(filter_h(h, b, gx, height, width, c, c3));
+    PAPOF_TRY(filter_v(h, b, gy, height, width, c, c3));
+    PAPOF_TRY(filter_v(h, gx, gxy, height, width, c, c3));
+    PAPOF_TRY(bicubic_warp(h, a, b, gx, gy, gxy, fx, fy, o, height, width, c));
+    PAPOF_HIP(hipMemcpyAsync(out, o, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    return PAPOF_OK;
+}
+
+// SOR micro-benchmark on synthetic planes resident in HBM: phi~U(0.5,50), imdx2/imdy2~U(0,.05),
+// imdxy~U(-.02,.02), rhs~U(-.01,.01); alpha .012, omega 1.8.
+int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_mode, int reps, unsigned seed,
+                    double* ms_per_solve) {
+    if (!h || !ms_per_solve || height < 1 || width < 1 || n_sor < 1 || reps < 1 || sor_mode < PAPOF_SOR_EXACT ||
+        sor_mode > PAPOF_SOR_JACOBI)
+        return PAPOF_EINVAL;
+    const size_t np = (size_t)height * width;
+    Scope S(h, img_bytes(height, width, 1, 16) + 12 * (skew_dims(height, width).n + 64) * sizeof(double));
+    PAPOF_TRY(S.rc);
+    std::vector<double> host(np * 6);
+    std::mt19937_64 rng(seed);
+    auto fill = [&](size_t k, double lo, double hi) {
+        std::uniform_real_distribution<double> d(lo, hi);
+        for (size_t i = 0; i < np; i++) host[k * np + i] = d(rng);
+    };
+    fill(0, 0.5, 50.0);
+    fill(1, -0.02, 0.02);
+    fill(2, 0.0, 0.05);
+    fill(3, 0.0, 0.05);
+    fill(4, -0.01, 0.01);
+    fill(5, -0.01, 0.01);
+    double* planes[6];
+    for (int k = 0; k < 6; k++) planes[k] = S.up_planar(host.data() + k * np, height, width, 1);
+    SorPlanes sp{};
+    PAPOF_TRY(alloc_sor_planes(S, height, width, sor_mode, sp));
+    PAPOF_TRY(sor_prep(h, planes[0], planes[1], planes[2], planes[3], planes[4], planes[5], height, width, 0.012, 1.8,
+                       sp));
+    PAPOF_TRY(sor_solve(h, sp, height, width, 0.012, 1.8, n_sor, sor_mode));  // warm-up
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    hipEvent_t e0, e1;
+    PAPOF_HIP(hipEventCreate(&e0));
+    PAPOF_HIP(hipEventCreate(&e1));
+    PAPOF_HIP(hipEventRecord(e0, h->stream));
+    for (int r = 0; r < reps; r++) PAPOF_TRY(sor_solve(h, sp, height, width, 0.012, 1.8, n_sor, sor_mode));
+    PAPOF_HIP(hipEventRecord(e1, h->stream));
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    PAPOF_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (sor_mode == PAPOF_SOR_EXACT) PAPOF_TRY(sor_check(h));
+    *ms_per_solve = (double)ms / reps;
+    return PAPOF_OK;
+}
+
+}  // extern "C"

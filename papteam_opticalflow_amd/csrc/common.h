@@ -1,0 +1,143 @@
+// papteam_opticalflow_amd/csrc/common.h -- shared host/device declarations of libpapof (gfx950 only).
+//
+// Device data layout (everything IEEE fp64, as the reference: typedef Image<double> DImage,
+// src/Image.h:469):
+//   * images / features are PLANAR: plane k of an H x W x C image is a dense row-major H*W array at
+//     base + k*H*W (the reference's interleaved HWC layout is converted once on entry and once on exit);
+//   * the eight SOR operands of the exact-order solver use the per-band SKEWED layout documented in
+//     sor.hip (64-row bands, element (r, j) of band b at ((b*NS + j + r)*64 + r), NS = W + 63).
+//
+// All device code is compiled with -ffp-contract=off: the reference is built without FMA
+// (Code/Serial/setup.py:24-25, plain x86-64 gcc), and matching its rounding step for step is what
+// makes the GPU results bit-compatible instead of merely close.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/papof.h"
+
+namespace papof {
+
+constexpr int kLanes = 64;     // CDNA wavefront
+constexpr int kMaxFsize = 8;   // Gaussian half-width supported by the filter kernels
+
+struct Taps {                  // 1-D correlation taps, passed by value as a kernel argument
+    double t[2 * kMaxFsize + 1];
+    int fsize;
+};
+
+// thread-local text of the last failing HIP call
+void set_last_error(const char* what, hipError_t e, const char* file, int line);
+const char* last_error();
+
+#define PAPOF_HIP(expr)                                              \
+    do {                                                             \
+        hipError_t _e = (expr);                                      \
+        if (_e != hipSuccess) {                                      \
+            ::papof::set_last_error(#expr, _e, __FILE__, __LINE__);  \
+            return PAPOF_EDEVICE;                                    \
+        }                                                            \
+    } while (0)
+
+#define PAPOF_TRY(expr)              \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != PAPOF_OK) return _rc; \
+    } while (0)
+
+// Bump arena over one hipMalloc'd block.  Stack discipline: mark()/release().
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    bool overflow = false;
+    void* alloc(size_t bytes) {
+        size_t o = (off + 255) & ~size_t(255);
+        if (o + bytes > cap) {
+            overflow = true;
+            return nullptr;
+        }
+        off = o + bytes;
+        if (off > peak) peak = off;
+        return base + o;
+    }
+    double* f64(size_t n) { return static_cast<double*>(alloc(n * sizeof(double))); }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+};
+
+struct SkewDims {
+    int nb;     // bands of 64 rows
+    int ns;     // steps per task = W + 63
+    size_t n;   // doubles per skewed plane
+};
+inline SkewDims skew_dims(int h, int w) {
+    SkewDims d;
+    d.nb = (h + kLanes - 1) / kLanes;
+    d.ns = w + kLanes - 1;
+    d.n = (size_t)d.nb * d.ns * kLanes;
+    return d;
+}
+
+// SOR operands of one solve.  `skew` selects the layout of all eight planes.
+struct SorPlanes {
+    double *phi, *xy, *a1, *a2, *b1, *b2;  // weights, imdxy, omega/diag_u, omega/diag_v, rhs_u, rhs_v
+    double *du, *dv;                       // unknowns (written from zero; no initialisation needed)
+    double *du2, *dv2;                     // Jacobi ping-pong (row-major modes only)
+    bool skew;
+};
+
+}  // namespace papof
+
+struct papof_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    papof::Arena arena;
+    unsigned* sync_words = nullptr;  // progress counters + abort word of the exact-order SOR
+    size_t sync_cap = 0;             // in unsigneds
+    unsigned* host_flag = nullptr;   // pinned mirror of the abort word
+    std::vector<hipEvent_t> events;
+    size_t events_used = 0;
+    int cu_count = 0;
+};
+
+namespace papof {
+
+// ---- kernels.hip: launch wrappers (all asynchronous on h->stream) ----
+int hwc_to_planar(papof_handle* h, const double* hwc, double* planar, int H, int W, int C);
+int planar_to_hwc(papof_handle* h, const double* planar, double* hwc, int H, int W, int C);
+int filter_h(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f);
+int filter_v(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f);
+int resize(papof_handle* h, const double* src, double* dst, int sh, int sw, int planes, int dh, int dw, double xr,
+           double yr, bool use_post, double post);
+int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C);
+int warp_bilinear(papof_handle* h, const double* im1, const double* im2, const double* vx, const double* vy,
+                  double* out, int H, int W, int planes);
+int smooth_v_blend(papof_handle* h, const double* tmp, const double* im1s, double* blend, double* imdt, int H,
+                   int W, int planes);
+int compute_phi(papof_handle* h, const double* u, const double* v, double* phi, int H, int W);
+int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,
+                    const double* v, int H, int W, int planes, double alpha, double omega, const SorPlanes& out,
+                    double* opt_imdx2, double* opt_imdy2);
+int laplacian(papof_handle* h, const double* in, const double* weight, double* out, int H, int W);
+int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, const double* im1,
+                    const double* im2, double* warp, int H, int W, int planes);
+int bicubic_warp(papof_handle* h, const double* im1, const double* im2, const double* gx, const double* gy,
+                 const double* gxy, const double* vx, const double* vy, double* out_hwc, int H, int W, int C);
+int sor_prep(papof_handle* h, const double* phi, const double* imdxy, const double* imdx2, const double* imdy2,
+             const double* rhs1, const double* rhs2, int H, int W, double alpha, double omega, const SorPlanes& out);
+int sor_unpack(papof_handle* h, const SorPlanes& sp, double* du, double* dv, int H, int W);
+Taps gaussian_taps(double sigma, int fsize);
+Taps smooth5_taps();
+Taps deriv5_taps();
+Taps central3_taps();
+
+// ---- sor.hip ----
+int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor, int mode);
+int sor_check(papof_handle* h);  // after a stream sync: PAPOF_ETIMEOUT if a device-side wait expired
+
+}  // namespace papof

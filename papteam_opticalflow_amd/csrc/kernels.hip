@@ -1,0 +1,639 @@
+// papteam_opticalflow_amd/csrc/kernels.hip -- every stage of the hot path except the SOR sweeps.
+//
+// One thread per output pixel, 64 x 4 thread blocks with threadIdx.x along the row so that each
+// wavefront reads/writes 512 contiguous bytes of a plane (planar fp64 layout, see common.h).
+// All kernels are HBM-bound stencils / gathers (no dense contraction => no MFMA).  Floating-point
+// operation ORDER follows the reference line by line (cited per kernel; paths relative to
+// /root/reference/Code/Serial/) because the parity bar is bit-compatibility, and the file is compiled
+// with -ffp-contract=off for the same reason.
+#include "common.h"
+
+#include <cmath>
+
+namespace papof {
+
+namespace {
+
+constexpr int BX = 64, BY = 4;
+
+inline dim3 grid2d(int W, int H, int planes = 1) { return dim3((W + BX - 1) / BX, (H + BY - 1) / BY, planes); }
+
+__device__ __forceinline__ int clampi(int x, int n) {  // EnforceRange, src/ImageProcessing.h:34
+    x = x < 0 ? 0 : x;
+    return x > n - 1 ? n - 1 : x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout conversion (entry / exit of the call): HWC interleaved <-> planar
+// ------------------------------------------------------------------------------------------------
+__global__ void k_hwc_to_planar(const double* __restrict__ hwc, double* __restrict__ planar, int H, int W, int C) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t o = (size_t)i * W + j, np = (size_t)H * W;
+    for (int k = 0; k < C; k++) planar[k * np + o] = hwc[o * C + k];
+}
+
+__global__ void k_planar_to_hwc(const double* __restrict__ planar, double* __restrict__ hwc, int H, int W, int C) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t o = (size_t)i * W + j, np = (size_t)H * W;
+    for (int k = 0; k < C; k++) hwc[o * C + k] = planar[k * np + o];
+}
+
+// ------------------------------------------------------------------------------------------------
+// separable correlation with clamped borders: src/ImageProcessing.h:259-279 (h), :350-369 (v).
+// Accumulation into a zeroed destination, taps in order l = -fsize..fsize.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_filter_h(const double* __restrict__ src, double* __restrict__ dst, int H, int W, Taps f) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t np = (size_t)H * W;
+    const double* row = src + blockIdx.z * np + (size_t)i * W;
+    double acc = 0.0;
+    for (int l = -f.fsize; l <= f.fsize; l++) acc += row[clampi(j + l, W)] * f.t[l + f.fsize];
+    dst[blockIdx.z * np + (size_t)i * W + j] = acc;
+}
+
+__global__ void k_filter_v(const double* __restrict__ src, double* __restrict__ dst, int H, int W, Taps f) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t np = (size_t)H * W;
+    const double* p = src + blockIdx.z * np + j;
+    double acc = 0.0;
+    for (int l = -f.fsize; l <= f.fsize; l++) acc += p[(size_t)clampi(i + l, H) * W] * f.t[l + f.fsize];
+    dst[blockIdx.z * np + (size_t)i * W + j] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear sampling: src/ImageProcessing.h:138-157.  Integer part by truncation toward zero,
+// fraction clamped to [0,1], taps visited x-offset outer / y-offset inner and ACCUMULATED from 0.
+// The four weights are shared by all planes of a pixel.
+// ------------------------------------------------------------------------------------------------
+struct BilinearTaps {
+    int o[4];     // plane offsets of the 4 taps in visiting order
+    double s[4];  // their weights
+};
+
+__device__ __forceinline__ BilinearTaps bilinear_taps(int W, int H, double x, double y) {
+    BilinearTaps b;
+    const int xx = (int)x, yy = (int)y;
+    double dx = x - xx, dy = y - yy;
+    dx = dx > 1 ? 1.0 : dx;
+    dx = dx < 0 ? 0.0 : dx;
+    dy = dy > 1 ? 1.0 : dy;
+    dy = dy < 0 ? 0.0 : dy;
+#pragma unroll
+    for (int m = 0; m <= 1; m++)
+#pragma unroll
+        for (int n = 0; n <= 1; n++) {
+            const int u = clampi(xx + m, W), v = clampi(yy + n, H);
+            b.o[m * 2 + n] = v * W + u;
+            b.s[m * 2 + n] = fabs((double)(1 - m) - dx) * fabs((double)(1 - n) - dy);
+        }
+    return b;
+}
+
+__device__ __forceinline__ double bilinear_apply(const double* __restrict__ p, const BilinearTaps& b) {
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc += p[b.o[t]] * b.s[t];
+    return acc;
+}
+
+// ImageProcessing::ResizeImage, src/ImageProcessing.h:214-253 (both overloads: xr == yr for the ratio form).
+// Optional post-scale = Image::Multiplywith (src/Image.h:1841-1850) for the flow up-sampling of
+// src/OpticalFlow.cpp:809-812.
+__global__ void k_resize(const double* __restrict__ src, double* __restrict__ dst, int sh, int sw, int dh, int dw,
+                         double xr, double yr, int use_post, double post) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= dw || i >= dh) return;
+    const double x = (double)(j + 1) / xr - 1;
+    const double y = (double)(i + 1) / yr - 1;
+    const BilinearTaps b = bilinear_taps(sw, sh, x, y);
+    double r = bilinear_apply(src + blockIdx.z * (size_t)sh * sw, b);
+    if (use_post) r *= post;
+    dst[blockIdx.z * (size_t)dh * dw + (size_t)i * dw + j] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// OpticalFlow::im2feature, src/OpticalFlow.cpp:911-961 (3-channel branch :934-955, 1-channel :918-933);
+// desaturate src/Image.h:1461-1480 with colorType RGB; 5-point derivative taps {1,-8,0,8,-1}/12
+// (src/Image.h:987-992) applied to the gray image with clamped borders.  Gray values of the stencil
+// neighbours are recomputed (same three-term expression => same bits) instead of staged.
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ double gray_at(const double* __restrict__ im, size_t np, size_t o) {
+    if (C == 3) return im[o] * .299 + im[np + o] * .587 + im[2 * np + o] * .114;
+    return im[o];
+}
+
+template <int C>
+__global__ void k_im2feature(const double* __restrict__ im, double* __restrict__ feat, int H, int W, Taps d) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t np = (size_t)H * W, o = (size_t)i * W + j;
+    double gx = 0.0, gy = 0.0;
+#pragma unroll
+    for (int l = -2; l <= 2; l++) gx += gray_at<C>(im, np, (size_t)i * W + clampi(j + l, W)) * d.t[l + 2];
+#pragma unroll
+    for (int l = -2; l <= 2; l++) gy += gray_at<C>(im, np, (size_t)clampi(i + l, H) * W + j) * d.t[l + 2];
+    feat[o] = gray_at<C>(im, np, o);
+    feat[np + o] = gx;
+    feat[2 * np + o] = gy;
+    if (C == 3) {
+        feat[3 * np + o] = im[np + o] - im[o];
+        feat[4 * np + o] = im[np + o] - im[2 * np + o];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// OpticalFlow::warpFL -> ImageProcessing::warpImage, src/ImageProcessing.h:483-503.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void warp_pixel(const double* __restrict__ im1, const double* __restrict__ im2,
+                                           double* __restrict__ out, double fx, double fy, int i, int j, int H,
+                                           int W, int planes) {
+    const size_t np = (size_t)H * W, o = (size_t)i * W + j;
+    const double y = i + fy;
+    const double x = j + fx;
+    if (x < 0 || x > W - 1 || y < 0 || y > H - 1) {
+        for (int k = 0; k < planes; k++) out[k * np + o] = im1[k * np + o];
+        return;
+    }
+    const BilinearTaps b = bilinear_taps(W, H, x, y);
+    for (int k = 0; k < planes; k++) out[k * np + o] = bilinear_apply(im2 + k * np, b);
+}
+
+__global__ void k_warp(const double* __restrict__ im1, const double* __restrict__ im2, const double* __restrict__ vx,
+                       const double* __restrict__ vy, double* __restrict__ out, int H, int W, int planes) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t o = (size_t)i * W + j;
+    warp_pixel(im1, im2, out, vx[o], vy[o], i, j, H, W, planes);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Second half of OpticalFlow::getDxs (src/OpticalFlow.cpp:89-97) for the warped frame: vertical pass of
+// the 5-tap smoothing, then Im = Im1s*0.4 + Im2s*0.6 (Multiplywith :92, Add(...,0.6) :93) and
+// imdt = Im2s - Im1s (:97).  Im1s (smoothed frame 1) is constant within a level and computed once.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_smooth_v_blend(const double* __restrict__ tmp, const double* __restrict__ im1s,
+                                 double* __restrict__ blend, double* __restrict__ imdt, int H, int W, Taps g) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t np = (size_t)H * W, o = blockIdx.z * np + (size_t)i * W + j;
+    const double* p = tmp + blockIdx.z * np + j;
+    double s2 = 0.0;
+#pragma unroll
+    for (int l = -2; l <= 2; l++) s2 += p[(size_t)clampi(i + l, H) * W] * g.t[l + 2];
+    const double s1 = im1s[o];
+    double t = s1;
+    t *= 0.4;
+    t += s2 * 0.6;
+    blend[o] = t;
+    imdt[o] = s2 - s1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// phi, src/OpticalFlow.cpp:295-331: forward differences of the flow (zero in the last column / row,
+// src/Image.h:979-986, :1022-1029) and phi = 0.5/sqrt(ux^2+uy^2+vx^2+vy^2+eps).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_phi(const double* __restrict__ u, const double* __restrict__ v, double* __restrict__ phi, int H,
+                      int W) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t o = (size_t)i * W + j;
+    const double uc = u[o], vc = v[o];
+    const double ux = j < W - 1 ? u[o + 1] - uc : 0.0;
+    const double uy = i < H - 1 ? u[o + W] - uc : 0.0;
+    const double vx = j < W - 1 ? v[o + 1] - vc : 0.0;
+    const double vy = i < H - 1 ? v[o + W] - vc : 0.0;
+    const double t = ux * ux + uy * uy + vx * vx + vy * vy;
+    phi[o] = 0.5 / sqrt(t + 0.001 * 0.001);
+}
+
+// index of cell (i, j) in an SOR operand plane
+template <bool SKEW>
+__device__ __forceinline__ size_t sor_index(int i, int j, int W, int ns) {
+    if (SKEW) {
+        const int b = i >> 6, r = i & 63;
+        return ((size_t)b * ns + (j + r)) * kLanes + r;
+    }
+    return (size_t)i * W + j;
+}
+
+// OpticalFlow::Laplacian at one cell, src/OpticalFlow.cpp:641-690: column W-1 receives no horizontal
+// term and row H-1 no vertical term (the loops stop at W-2 / H-2).
+__device__ __forceinline__ double laplacian_at(const double* __restrict__ in, const double* __restrict__ wt, int i,
+                                               int j, int H, int W) {
+    const size_t o = (size_t)i * W + j;
+    const double c = in[o];
+    double out = 0.0;
+    if (j < W - 1) {
+        out -= (in[o + 1] - c) * wt[o];
+        if (j > 0) out += (c - in[o - 1]) * wt[o - 1];
+    }
+    if (i < H - 1) {
+        out -= (in[o + W] - c) * wt[o];
+        if (i > 0) out += (c - in[o - W]) * wt[o - W];
+    }
+    return out;
+}
+
+__global__ void k_laplacian(const double* __restrict__ in, const double* __restrict__ wt, double* __restrict__ out,
+                            int H, int W) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    out[(size_t)i * W + j] = laplacian_at(in, wt, i, j, H, W);
+}
+
+// diagonal terms of the SOR update, src/OpticalFlow.cpp:468-501: coeff accumulated left, right, up, down,
+// scaled by alpha; a = omega / (imd?2 + alpha*0.05 + coeff).  They do not change during the sweeps, so
+// the two divisions per cell-update of the reference are hoisted out of the sweep loop (same bits:
+// the reference evaluates (omega/denominator) * (rhs - sigma) left to right).
+__device__ __forceinline__ void sor_diagonals(const double* __restrict__ phi, int i, int j, int H, int W,
+                                              double imdx2, double imdy2, double alpha, double omega, double& a1,
+                                              double& a2) {
+    const size_t o = (size_t)i * W + j;
+    double coeff = 0.0;
+    if (j > 0) coeff += phi[o - 1];
+    if (j < W - 1) coeff += phi[o];
+    if (i > 0) coeff += phi[o - W];
+    if (i < H - 1) coeff += phi[o];
+    coeff *= alpha;
+    a1 = omega / (imdx2 + alpha * 0.05 + coeff);
+    a2 = omega / (imdy2 + alpha * 0.05 + coeff);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused assembly of the linear system of one fixed-point iteration (du = dv = 0, i.e. nInner == 1):
+//   imdx/imdy  = 5-point derivatives of the blended image, src/OpticalFlow.cpp:95-96 (computed inline)
+//   psi        = 1/(2 sqrt(imdt^2 + eps)) per channel, :377-406
+//   imdxy,...  = channel means of (psi*a)*b, :414-427 with src/Image.h:1747-1763 and :1537-1545
+//   rhs        = -imdtd? - alpha*Laplacian(flow, phi), :437-448
+//   a1, a2     = hoisted SOR diagonals (above)
+// Reads 2*planes + 3 streams, writes 6 SOR operand planes in the layout the solver wants.
+// ------------------------------------------------------------------------------------------------
+template <bool SKEW>
+__global__ void k_assemble(const double* __restrict__ blend, const double* __restrict__ imdt,
+                           const double* __restrict__ phi, const double* __restrict__ u,
+                           const double* __restrict__ v, int H, int W, int planes, double alpha, double omega,
+                           int ns, double* __restrict__ o_phi, double* __restrict__ o_xy, double* __restrict__ o_a1,
+                           double* __restrict__ o_a2, double* __restrict__ o_b1, double* __restrict__ o_b2,
+                           double* __restrict__ o_x2, double* __restrict__ o_y2, Taps d) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t np = (size_t)H * W, o = (size_t)i * W + j;
+    double sxy = 0.0, sx2 = 0.0, sy2 = 0.0, stx = 0.0, sty = 0.0;
+    for (int k = 0; k < planes; k++) {
+        const double* im = blend + k * np;
+        double gx = 0.0, gy = 0.0;
+#pragma unroll
+        for (int l = -2; l <= 2; l++) gx += im[(size_t)i * W + clampi(j + l, W)] * d.t[l + 2];
+#pragma unroll
+        for (int l = -2; l <= 2; l++) gy += im[(size_t)clampi(i + l, H) * W + j] * d.t[l + 2];
+        const double gt = imdt[k * np + o];
+        double t = gt;  // imdt + imdx*du + imdy*dv with du = dv = 0
+        t *= t;
+        const double psi = 1 / (2 * sqrt(t + 0.001 * 0.001));
+        const double pgx = psi * gx, pgy = psi * gy;
+        if (planes == 1) {
+            sxy = pgx * gy;
+            sx2 = pgx * gx;
+            sy2 = pgy * gy;
+            stx = pgx * gt;
+            sty = pgy * gt;
+        } else {
+            sxy += pgx * gy;
+            sx2 += pgx * gx;
+            sy2 += pgy * gy;
+            stx += pgx * gt;
+            sty += pgy * gt;
+        }
+    }
+    if (planes > 1) {
+        sxy = sxy / planes;
+        sx2 = sx2 / planes;
+        sy2 = sy2 / planes;
+        stx = stx / planes;
+        sty = sty / planes;
+    }
+    const double b1 = -stx - alpha * laplacian_at(u, phi, i, j, H, W);
+    const double b2 = -sty - alpha * laplacian_at(v, phi, i, j, H, W);
+    double a1, a2;
+    sor_diagonals(phi, i, j, H, W, sx2, sy2, alpha, omega, a1, a2);
+    const size_t q = sor_index<SKEW>(i, j, W, ns);
+    o_phi[q] = phi[o];
+    o_xy[q] = sxy;
+    o_a1[q] = a1;
+    o_a2[q] = a2;
+    o_b1[q] = b1;
+    o_b2[q] = b2;
+    if (o_x2) o_x2[o] = sx2;
+    if (o_y2) o_y2[o] = sy2;
+}
+
+// stage helper: SOR operands from already assembled row-major planes (tests / micro-benchmark)
+template <bool SKEW>
+__global__ void k_sor_prep(const double* __restrict__ phi, const double* __restrict__ imdxy,
+                           const double* __restrict__ imdx2, const double* __restrict__ imdy2,
+                           const double* __restrict__ rhs1, const double* __restrict__ rhs2, int H, int W,
+                           double alpha, double omega, int ns, double* __restrict__ o_phi,
+                           double* __restrict__ o_xy, double* __restrict__ o_a1, double* __restrict__ o_a2,
+                           double* __restrict__ o_b1, double* __restrict__ o_b2) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t o = (size_t)i * W + j;
+    double a1, a2;
+    sor_diagonals(phi, i, j, H, W, imdx2[o], imdy2[o], alpha, omega, a1, a2);
+    const size_t q = sor_index<SKEW>(i, j, W, ns);
+    o_phi[q] = phi[o];
+    o_xy[q] = imdxy[o];
+    o_a1[q] = a1;
+    o_a2[q] = a2;
+    o_b1[q] = rhs1[o];
+    o_b2[q] = rhs2[o];
+}
+
+template <bool SKEW>
+__global__ void k_sor_unpack(const double* __restrict__ sdu, const double* __restrict__ sdv,
+                             double* __restrict__ du, double* __restrict__ dv, int H, int W, int ns) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t q = sor_index<SKEW>(i, j, W, ns), o = (size_t)i * W + j;
+    du[o] = sdu[q];
+    dv[o] = sdv[q];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase 6, src/OpticalFlow.cpp:513-516: u += du, v += dv (Image::Add, src/Image.h:1925-1941) and re-warp
+// frame 2 with the updated flow -- fused, the update of a pixel only feeds its own warp.
+// ------------------------------------------------------------------------------------------------
+template <bool SKEW>
+__global__ void k_update_warp(const double* __restrict__ sdu, const double* __restrict__ sdv, double* __restrict__ u,
+                              double* __restrict__ v, const double* __restrict__ im1,
+                              const double* __restrict__ im2, double* __restrict__ warp, int H, int W, int planes,
+                              int ns) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t q = sor_index<SKEW>(i, j, W, ns), o = (size_t)i * W + j;
+    double fu = u[o], fv = v[o];
+    fu += sdu[q];
+    fv += sdv[q];
+    u[o] = fu;
+    v[o] = fv;
+    warp_pixel(im1, im2, warp, fu, fv, i, j, H, W, planes);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Final warp of the ORIGINAL frames: Image::warpImageBicubicRef src/Image.h:2624-2701 with the Hermite
+// coefficients of BicubicCoeff :2497-2530, then threshold() :2031-2045.  gx, gy, gxy are the central
+// differences {-0.5,0,0.5} of frame 2 (imfilter_h / imfilter_v / imfilter_v(gx), :2590-2594).
+// Corners A=(x0,y0) B=(x1,y0) C=(x0,y1) D=(x1,y1); cXY multiplies dx^X dy^Y; term order as in the
+// reference expressions.  Output goes straight to the interleaved HWC buffer handed back to the caller.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_bicubic(const double* __restrict__ im1, const double* __restrict__ im2,
+                          const double* __restrict__ gx, const double* __restrict__ gy,
+                          const double* __restrict__ gxy, const double* __restrict__ vx,
+                          const double* __restrict__ vy, double* __restrict__ out, int H, int W, int C) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t np = (size_t)H * W, o = (size_t)i * W + j;
+    const double x = j + vx[o];
+    const double y = i + vy[o];
+    if (x < 0 || x > W - 1 || y < 0 || y > H - 1) {
+        for (int k = 0; k < C; k++) {
+            double r = im1[k * np + o];
+            r = r < 0 ? 0.0 : r;
+            r = r > 1 ? 1.0 : r;
+            out[o * C + k] = r;
+        }
+        return;
+    }
+    int x0 = (int)x, y0 = (int)y;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 = clampi(x0, W);
+    x1 = clampi(x1, W);
+    y0 = clampi(y0, H);
+    y1 = clampi(y1, H);
+    const double dx = x - x0, dy = y - y0;
+    const double dx2 = dx * dx, dy2 = dy * dy;
+    const double dx3 = dx * dx2, dy3 = dy * dy2;
+    const size_t a = (size_t)y0 * W + x0, b = (size_t)y0 * W + x1, c = (size_t)y1 * W + x0, d = (size_t)y1 * W + x1;
+    for (int k = 0; k < C; k++) {
+        const double *f = im2 + k * np, *px = gx + k * np, *py = gy + k * np, *pz = gxy + k * np;
+        const double fA = f[a], fB = f[b], fC = f[c], fD = f[d];
+        const double xA = px[a], xB = px[b], xC = px[c], xD = px[d];
+        const double yA = py[a], yB = py[b], yC = py[c], yD = py[d];
+        const double zA = pz[a], zB = pz[b], zC = pz[c], zD = pz[d];
+        const double c00 = fA;
+        const double c10 = xA;
+        const double c20 = -3 * fA + 3 * fB - 2 * xA - xB;
+        const double c30 = 2 * fA - 2 * fB + xA + xB;
+        const double c01 = yA;
+        const double c11 = zA;
+        const double c21 = -3 * yA + 3 * yB - 2 * zA - zB;
+        const double c31 = 2 * yA - 2 * yB + zA + zB;
+        const double c02 = -3 * fA + 3 * fC - 2 * yA - yC;
+        const double c12 = -3 * xA + 3 * xC - 2 * zA - zC;
+        const double c22 = 9 * fA - 9 * fB - 9 * fC + 9 * fD + 6 * xA + 3 * xB - 6 * xC - 3 * xD + 6 * yA - 6 * yB +
+                           3 * yC - 3 * yD + 4 * zA + 2 * zB + 2 * zC + zD;
+        const double c32 = -6 * fA + 6 * fB + 6 * fC - 6 * fD - 3 * xA - 3 * xB + 3 * xC + 3 * xD - 4 * yA + 4 * yB -
+                           2 * yC + 2 * yD - 2 * zA - 2 * zB - zC - zD;
+        const double c03 = 2 * fA - 2 * fC + yA + yC;
+        const double c13 = 2 * xA - 2 * xC + zA + zC;
+        const double c23 = -6 * fA + 6 * fB + 6 * fC - 6 * fD - 4 * xA - 2 * xB + 4 * xC + 2 * xD - 3 * yA + 3 * yB -
+                           3 * yC + 3 * yD - 2 * zA - zB - 2 * zC - zD;
+        const double c33 = 4 * fA - 4 * fB - 4 * fC + 4 * fD + 2 * xA + 2 * xB - 2 * xC - 2 * xD + 2 * yA - 2 * yB +
+                           2 * yC - 2 * yD + zA + zB + zC + zD;
+        double r = c00 + c01 * dy + c02 * dy2 + c03 * dy3 + c10 * dx + c11 * dx * dy + c12 * dx * dy2 +
+                   c13 * dx * dy3 + c20 * dx2 + c21 * dx2 * dy + c22 * dx2 * dy2 + c23 * dx2 * dy3 + c30 * dx3 +
+                   c31 * dx3 * dy + c32 * dx3 * dy2 + c33 * dx3 * dy3;
+        r = r < 0 ? 0.0 : r;
+        r = r > 1 ? 1.0 : r;
+        out[o * C + k] = r;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+// host-side tap tables and launch wrappers
+// ================================================================================================
+Taps gaussian_taps(double sigma, int fsize) {  // src/Image.h:1203-1219
+    Taps f{};
+    f.fsize = fsize;
+    double sum = 0;
+    const double s2 = sigma * sigma * 2;
+    for (int i = -fsize; i <= fsize; i++) {
+        f.t[i + fsize] = std::exp(-(double)(i * i) / s2);
+        sum += f.t[i + fsize];
+    }
+    for (int i = 0; i < 2 * fsize + 1; i++) f.t[i] /= sum;
+    return f;
+}
+
+Taps smooth5_taps() {  // src/OpticalFlow.cpp:84
+    Taps f{};
+    f.fsize = 2;
+    const double g[5] = {0.02, 0.11, 0.74, 0.11, 0.02};
+    for (int i = 0; i < 5; i++) f.t[i] = g[i];
+    return f;
+}
+
+Taps deriv5_taps() {  // src/Image.h:987-992
+    Taps f{};
+    f.fsize = 2;
+    const double d[5] = {1, -8, 0, 8, -1};
+    for (int i = 0; i < 5; i++) {
+        f.t[i] = d[i];
+        f.t[i] /= 12;
+    }
+    return f;
+}
+
+Taps central3_taps() {  // src/Image.h:2589
+    Taps f{};
+    f.fsize = 1;
+    f.t[0] = -0.5;
+    f.t[1] = 0;
+    f.t[2] = 0.5;
+    return f;
+}
+
+#define LAUNCH_CHECK() PAPOF_HIP(hipGetLastError())
+
+int hwc_to_planar(papof_handle* h, const double* hwc, double* planar, int H, int W, int C) {
+    hipLaunchKernelGGL(k_hwc_to_planar, grid2d(W, H), dim3(BX, BY), 0, h->stream, hwc, planar, H, W, C);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int planar_to_hwc(papof_handle* h, const double* planar, double* hwc, int H, int W, int C) {
+    hipLaunchKernelGGL(k_planar_to_hwc, grid2d(W, H), dim3(BX, BY), 0, h->stream, planar, hwc, H, W, C);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int filter_h(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f) {
+    hipLaunchKernelGGL(k_filter_h, grid2d(W, H, planes), dim3(BX, BY), 0, h->stream, src, dst, H, W, f);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int filter_v(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f) {
+    hipLaunchKernelGGL(k_filter_v, grid2d(W, H, planes), dim3(BX, BY), 0, h->stream, src, dst, H, W, f);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int resize(papof_handle* h, const double* src, double* dst, int sh, int sw, int planes, int dh, int dw, double xr,
+           double yr, bool use_post, double post) {
+    hipLaunchKernelGGL(k_resize, grid2d(dw, dh, planes), dim3(BX, BY), 0, h->stream, src, dst, sh, sw, dh, dw, xr,
+                       yr, use_post ? 1 : 0, post);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C) {
+    if (C == 3) {
+        hipLaunchKernelGGL(k_im2feature<3>, grid2d(W, H), dim3(BX, BY), 0, h->stream, im, feat, H, W, deriv5_taps());
+    } else if (C == 1) {
+        hipLaunchKernelGGL(k_im2feature<1>, grid2d(W, H), dim3(BX, BY), 0, h->stream, im, feat, H, W, deriv5_taps());
+    } else {  // src/OpticalFlow.cpp:956-957: any other channel count is passed through
+        PAPOF_HIP(hipMemcpyAsync(feat, im, sizeof(double) * (size_t)H * W * C, hipMemcpyDeviceToDevice, h->stream));
+        return PAPOF_OK;
+    }
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int warp_bilinear(papof_handle* h, const double* im1, const double* im2, const double* vx, const double* vy,
+                  double* out, int H, int W, int planes) {
+    hipLaunchKernelGGL(k_warp, grid2d(W, H), dim3(BX, BY), 0, h->stream, im1, im2, vx, vy, out, H, W, planes);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int smooth_v_blend(papof_handle* h, const double* tmp, const double* im1s, double* blend, double* imdt, int H,
+                   int W, int planes) {
+    hipLaunchKernelGGL(k_smooth_v_blend, grid2d(W, H, planes), dim3(BX, BY), 0, h->stream, tmp, im1s, blend, imdt,
+                       H, W, smooth5_taps());
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int compute_phi(papof_handle* h, const double* u, const double* v, double* phi, int H, int W) {
+    hipLaunchKernelGGL(k_phi, grid2d(W, H), dim3(BX, BY), 0, h->stream, u, v, phi, H, W);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,
+                    const double* v, int H, int W, int planes, double alpha, double omega, const SorPlanes& out,
+                    double* opt_imdx2, double* opt_imdy2) {
+    const int ns = skew_dims(H, W).ns;
+    if (out.skew)
+        hipLaunchKernelGGL(k_assemble<true>, grid2d(W, H), dim3(BX, BY), 0, h->stream, blend, imdt, phi, u, v, H, W,
+                           planes, alpha, omega, ns, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2, opt_imdx2,
+                           opt_imdy2, deriv5_taps());
+    else
+        hipLaunchKernelGGL(k_assemble<false>, grid2d(W, H), dim3(BX, BY), 0, h->stream, blend, imdt, phi, u, v, H,
+                           W, planes, alpha, omega, ns, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2, opt_imdx2,
+                           opt_imdy2, deriv5_taps());
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int laplacian(papof_handle* h, const double* in, const double* weight, double* out, int H, int W) {
+    hipLaunchKernelGGL(k_laplacian, grid2d(W, H), dim3(BX, BY), 0, h->stream, in, weight, out, H, W);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, const double* im1,
+                    const double* im2, double* warp, int H, int W, int planes) {
+    const int ns = skew_dims(H, W).ns;
+    if (sp.skew)
+        hipLaunchKernelGGL(k_update_warp<true>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, u, v, im1,
+                           im2, warp, H, W, planes, ns);
+    else
+        hipLaunchKernelGGL(k_update_warp<false>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, u, v, im1,
+                           im2, warp, H, W, planes, ns);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int bicubic_warp(papof_handle* h, const double* im1, const double* im2, const double* gx, const double* gy,
+                 const double* gxy, const double* vx, const double* vy, double* out_hwc, int H, int W, int C) {
+    hipLaunchKernelGGL(k_bicubic, grid2d(W, H), dim3(BX, BY), 0, h->stream, im1, im2, gx, gy, gxy, vx, vy, out_hwc,
+                       H, W, C);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int sor_prep(papof_handle* h, const double* phi, const double* imdxy, const double* imdx2, const double* imdy2,
+             const double* rhs1, const double* rhs2, int H, int W, double alpha, double omega, const SorPlanes& out) {
+    const int ns = skew_dims(H, W).ns;
+    if (out.skew)
+        hipLaunchKernelGGL(k_sor_prep<true>, grid2d(W, H), dim3(BX, BY), 0, h->stream, phi, imdxy, imdx2, imdy2,
+                           rhs1, rhs2, H, W, alpha, omega, ns, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2);
+    else
+        hipLaunchKernelGGL(k_sor_prep<false>, grid2d(W, H), dim3(BX, BY), 0, h->stream, phi, imdxy, imdx2, imdy2,
+                           rhs1, rhs2, H, W, alpha, omega, ns, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int sor_unpack(papof_handle* h, const SorPlanes& sp, double* du, double* dv, int H, int W) {
+    const int ns = skew_dims(H, W).ns;
+    if (sp.skew)
+        hipLaunchKernelGGL(k_sor_unpack<true>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, du, dv, H, W,
+                           ns);
+    else
+        hipLaunchKernelGGL(k_sor_unpack<false>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, du, dv, H,
+                           W, ns);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+}  // namespace papof

@@ -1,0 +1,84 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol include/papof.h declares, and
+fails LOUDLY (no CPU fallback) when there is no GPU.  No compute call is made here."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from papteam_opticalflow_amd import capi
+    if not os.path.exists(capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return capi.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from papteam_opticalflow_amd import capi
+    header = open(os.path.join(ROOT, "include", "papof.h")).read()
+    declared = sorted(set(re.findall(r"\b(papof_[a-z0-9_A-Z]+)\s*\(", header)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), "libpapof.so does not export " + name
+    assert sorted(capi.SYMBOLS) == declared
+
+
+def test_defaults_are_the_reference_constants(lib):
+    from papteam_opticalflow_amd import capi
+    p = capi.default_params()
+    # src/OpticalFlow.cpp:747-751, :451, :823
+    assert (p.alpha, p.ratio, p.n_outer, p.n_outer_per_level, p.n_inner, p.n_sor, p.n_sor_per_level, p.omega,
+            p.sor_mode) == (0.012, 0.75, 7, 1, 1, 30, 3, 1.8, 0)
+    assert capi.timing_keys() == sorted(capi.timing_keys())  # std::map order
+    assert capi.timing_keys()[-1] == "Total C++ Execution"
+    assert capi.format_timing([0.5] * 10)["Allocation"] == "0.500000"  # std::to_string(double)
+
+
+def test_library_does_not_link_the_oracle():
+    """The product path must not route through the checker."""
+    import subprocess
+    from papteam_opticalflow_amd import capi
+    out = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "papof_ref" not in out
+    for root, _, files in os.walk(os.path.join(ROOT, "papteam_opticalflow_amd")):
+        for f in files:
+            if f.endswith((".py", ".pyx", ".hip", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert "libpapof_oracle" not in text and "import _libs" not in text, f
+
+
+def test_no_gpu_means_loud_failure(lib):
+    from papteam_opticalflow_amd import capi
+    if lib.papof_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.PapofError) as e:
+        capi.Papof(0)
+    assert e.value.code == -2
+    import papteam_opticalflow_amd as pkg
+    with pytest.raises(capi.PapofError):
+        pkg.coarse2fine_flow(np.zeros((8, 8, 3)), np.zeros((8, 8, 3)), 2)
+
+
+def test_pyflow_argument_checks_without_gpu(lib):
+    sys.path.insert(0, os.path.join(ROOT, "papteam_opticalflow_amd", "dropin"))
+    import pyflow
+    a = np.zeros((8, 8, 3))
+    with pytest.raises(ValueError):
+        pyflow.coarse2fine_flow(a, np.zeros((8, 9, 3)), 2)
+    with pytest.raises(ValueError):
+        pyflow.coarse2fine_flow(a, a, 0)
+    with pytest.raises(TypeError):
+        pyflow.coarse2fine_flow(a, None, 2)
+    with pytest.raises(ValueError):
+        pyflow.coarse2fine_flow(a.astype(np.float32), a.astype(np.float32), 2)
+    with pytest.raises(TypeError):
+        pyflow.coarse2fine_flow(a, a, 2, bogus=1)
+    if lib.papof_device_count() == 0:
+        with pytest.raises(RuntimeError):
+            pyflow.coarse2fine_flow(a, a, 2)
