@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpix/s per frame pair at 1920x1080 with a fixed SOR schedule (BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete coarse-to-fine solve of one frame pair (pyramid, every outer iteration, every SOR sweep,
+final bicubic warp) through the C ABI (papof_flow_device) with both frames already resident in HBM when the timed
+region starts.  Workload at N=1 = BASELINE.json configs[3]: 1920x1080 pair, 5 pyramid levels, 3 outer / 30 SOR
+iterations at every level, exact (reference-order) SOR, fp64.  N>1 = replicas, one independent frame pair per GPU
+(weak scaling, no data-path collective; see DESIGN.md "Multi-GPU").
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- for the dominant kernel (k_sor_exact): algorithmic bytes (80 B per cell-update)
+                  of all SOR launches of a step / their summed duration, measured live with HIP events recorded on
+                  the library's own stream around every SOR launch inside the timed region;
+  cpu_baseline -- the same workload run once on ONE host core by the untouched reference (oracle/_ref, kind
+                  "reference") when its prebuilt .so travelled with the snapshot, else by our CPU restatement
+                  (oracle/, kind "port").  Checker code, used here only as the timed CPU baseline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+SCHEDULES = {  # (n_outer, outer_per_level, n_sor, sor_per_level)
+    "cfg4": (3, 0, 30, 0),       # BASELINE.json configs[3]: "3 outer / 30 SOR iters"
+    "reference": (7, 1, 30, 3),  # the reference's hard-coded schedule (src/OpticalFlow.cpp:749-751,823)
+}
+MODES = {"exact": 0, "redblack": 1, "jacobi": 2}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+BYTES_PER_UPDATE = 80  # 8 fp64 reads + 2 fp64 writes per cell-update (SURVEY.md §8d / BASELINE.md §3)
+
+
+def load_frames(res):
+    try:
+        import cases
+        a, b = cases.load_pair(res)
+        return a, b, "HoChiMinhTraffic_10FPS_%s frame_00001->00002 (committed fixture of the reference's set)" % res
+    except Exception:
+        h, w = {"240": (135, 240), "480": (270, 480), "960": (540, 960), "1920": (1080, 1920)}[res]
+        rng = np.random.default_rng(0)
+        a = rng.uniform(0, 1, (h // 8 + 2, w // 8 + 2, 3)).repeat(8, 0).repeat(8, 1)[:h, :w]
+        b = np.roll(a, (1, 2), (0, 1)) + rng.normal(0, 0.01, a.shape)
+        return np.ascontiguousarray(a), np.ascontiguousarray(np.clip(b, 0, 1)), "synthetic"
+
+
+def level_dims(gpu, h, w, levels):
+    import ctypes
+    dims = np.zeros(2 * levels, dtype=np.int32)
+    n = ctypes.c_long(0)
+    rc = gpu.L.papof_stage_pyramid(gpu.h, None, h, w, 3, 0.75, levels, dims.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                   None, ctypes.byref(n))
+    assert rc == 0
+    return [(int(dims[2 * i]), int(dims[2 * i + 1])) for i in range(levels)]
+
+
+def cpu_baseline(a, b, levels, sched, mode):
+    from _libs import OracleLib, RefLib
+    kind, lib = "port", None
+    if mode == 0 and RefLib.available():
+        try:
+            lib, kind = RefLib(), "reference"
+        except OSError:
+            lib = None
+    if lib is None:
+        lib = OracleLib()
+    t0 = time.perf_counter()
+    lib.coarse2fine_flow_sched(a, b, levels, 0.012, 0.75, sched[0], sched[1], 1, sched[2], sched[3], mode=mode,
+                               omega=1.8 if mode != 2 else 1.0)
+    dt = time.perf_counter() - t0
+    return kind, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--res", default="1920", choices=["240", "480", "960", "1920"])
+    ap.add_argument("--levels", type=int, default=5)
+    ap.add_argument("--schedule", default="cfg4", choices=sorted(SCHEDULES))
+    ap.add_argument("--mode", default="exact", choices=sorted(MODES))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from papteam_opticalflow_amd import Papof, default_params
+    gpu = Papof(local_rank)
+    a, b, data_desc = load_frames(args.res)
+    h, w, c = a.shape
+    sched, mode = SCHEDULES[args.schedule], MODES[args.mode]
+    P = default_params(n_outer=sched[0], n_outer_per_level=sched[1], n_sor=sched[2], n_sor_per_level=sched[3],
+                       sor_mode=mode, omega=1.8 if mode != 2 else 1.0, phase_timing=0)
+    d1, d2 = gpu.dev_alloc(a.nbytes), gpu.dev_alloc(b.nbytes)
+    dvx, dvy, dwp = gpu.dev_alloc(h * w * 8), gpu.dev_alloc(h * w * 8), gpu.dev_alloc(a.nbytes)
+    gpu.dev_upload(d1, a)  # inputs resident in HBM before the timed region
+    gpu.dev_upload(d2, b)
+
+    def sync_all():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        gpu.flow_device(d1, d2, h, w, c, args.levels, P, dvx, dvy, dwp)
+    sync_all()
+    t0 = time.perf_counter()
+    sor_sec = 0.0
+    for _ in range(args.steps):
+        t = gpu.flow_device(d1, d2, h, w, c, args.levels, P, dvx, dvy, dwp)  # returns after its stream drained
+        sor_sec += t[6]
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * (h * w / 1e6) / (elapsed / args.steps)
+        dims = level_dims(gpu, h, w, args.levels)
+        updates = sum(lw * lh * (sched[0] + k * sched[1]) * (sched[2] + k * sched[3]) for k, (lw, lh) in enumerate(dims))
+        launches = sum(sched[0] + k * sched[1] for k in range(args.levels)) * (1 if mode == 0 else 0)
+        sor_step = sor_sec / args.steps
+        achieved = updates * BYTES_PER_UPDATE / 1e9 / sor_step if sor_step > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("%s_%s_%s" % (args.res, args.schedule, args.mode))
+            except Exception:
+                traffic = None
+        # parity statistic of the metric: max-abs delta (u, v) against the untouched reference's golden values
+        parity = None
+        try:
+            import cases
+            gold = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
+            key = {("1920", "cfg4", 5): "cfg4_1920_L5", ("1920", "reference", 5): "e2e_1920_L5",
+                   ("480", "cfg4", 5): "cfg4_480_L5", ("960", "reference", 5): "e2e_960_L5"}.get(
+                       (args.res, args.schedule, args.levels))
+            if key and mode == 0:
+                vx, vy = np.zeros((h, w)), np.zeros((h, w))
+                gpu.dev_download(vx, dvx)
+                gpu.dev_download(vy, dvy)
+                parity = float(max(np.abs(cases.subsample(vx) - gold[key + "|vx"]).max(),
+                                   np.abs(cases.subsample(vy) - gold[key + "|vy"]).max()))
+        except Exception:
+            parity = None
+        out = {
+            "metric": "Mpix/s per frame-pair (fixed SOR iters) at 1920x1080; max-abs d(u,v) vs ref",
+            "value": round(value, 4), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": data_desc,
+            "config": {"workload": "%dx%d frame pair, %d-level pyramid, schedule %s (outer %d+%dk, SOR %d+%dk), "
+                                   "%s-order SOR" % (w, h, args.levels, args.schedule, sched[0], sched[1], sched[2],
+                                                     sched[3], args.mode),
+                       "parallelism": "replicas: one independent frame pair per GPU" if world > 1 else "1 GPU"},
+            "max_abs_duv_vs_reference": parity,
+            "roofline": {"bound": "hbm", "kernel": "k_sor_exact" if mode == 0 else "k_sor_" + args.mode,
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "launches_per_step": launches, "cell_updates_per_step": updates,
+                         "avg_launch_ms": round(sor_step * 1e3 / launches, 4) if launches else None,
+                         "sor_ms_per_step": round(sor_step * 1e3, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            kind, dt = cpu_baseline(a, b, args.levels, sched, mode)
+            out["cpu_baseline"] = {"value": round(h * w / 1e6 / dt, 5), "unit": "Mpix/s", "cores": 1, "kind": kind,
+                                   "sample": "the same %dx%d pair and schedule, one full solve (%.1f s), single "
+                                             "thread (the reference Serial path is single-threaded)" % (w, h, dt),
+                                   "host_cpus": os.cpu_count()}
+        print(json.dumps(out), flush=True)
+    for p in (d1, d2, dvx, dvy, dwp):
+        gpu.dev_free(p)
+    gpu.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

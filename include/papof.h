@@ -59,8 +59,8 @@ typedef struct papof_params {
     int n_sor_per_level;   /* 3      ... plus this many per pyramid level k     :823 (nCG+k*3)          */
     double omega;          /* 1.8    over-relaxation factor                     :451                    */
     int sor_mode;          /* PAPOF_SOR_*                                                                */
-    int phase_timing;      /* 0: only Total/Construction/PostProcessing are measured (no extra syncs);
-                              1: all ten reference timers via HIP events                                */
+    int phase_timing;      /* 0: only "Total C++ Execution" and "Phase5_SOR" are measured (HIP events around
+                              the call and around each SOR launch); 1: all ten reference timers             */
 } papof_params;
 
 /* Index of each reference timer in timing_sec[] == sorted std::map key order, src/OpticalFlow.cpp:850-860 */
