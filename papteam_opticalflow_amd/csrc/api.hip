@@ -4,6 +4,7 @@
 //
 // One call = one H2D of the two frames, every pyramid level / outer iteration / sweep on the device
 // (single stream, no host round trip in between), one D2H of vx, vy, warpI2.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -304,6 +305,7 @@ int flow_device(papof_handle* h, const double* d_im1, const double* d_im2, int H
             std::swap(v, v2);
             PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc));
         }
+        PAPOF_TRY(sor_reset_planes(h, B.sp, lh, lw));
         PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, lh, lw, fc, P.alpha, P.n_outer + k * P.n_outer_per_level,
                               P.n_sor + k * P.n_sor_per_level, P.omega, P.sor_mode, B, clk, sorclk));
         pw = lw;
@@ -418,6 +420,12 @@ int papof_create(int device, papof_handle** out) {
         set_last_error("hipStreamCreate", e, __FILE__, __LINE__);
         delete h;
         return PAPOF_ENODEVICE;
+    }
+    if (const char* cs = std::getenv("PAPOF_SOR_CHUNK")) h->sor_chunk = std::max(8, std::atoi(cs));
+    int rc = sor_probe_dpp(h);
+    if (rc != PAPOF_OK) {
+        papof_destroy(h);
+        return rc;
     }
     *out = h;
     return PAPOF_OK;
@@ -828,6 +836,7 @@ int papof_stage_sor(papof_handle* h, const double* phi, const double* imdxy, con
     double *ou = S.dev(np), *ov = S.dev(np);
     SorPlanes sp{};
     PAPOF_TRY(alloc_sor_planes(S, height, width, sor_mode, sp));
+    PAPOF_TRY(sor_reset_planes(h, sp, height, width));
     PAPOF_TRY(sor_prep(h, p, xy, x2, y2, r1, r2, height, width, alpha, omega, sp));
     PAPOF_TRY(sor_solve(h, sp, height, width, alpha, omega, n_sor, sor_mode));
     PAPOF_TRY(sor_unpack(h, sp, ou, ov, height, width));
@@ -855,6 +864,7 @@ int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2
     PAPOF_TRY(S.rc);
     SolveBuffers B;
     PAPOF_TRY(alloc_solve_buffers(h->arena, height, width, c, sor_mode, B));
+    PAPOF_TRY(sor_reset_planes(h, B.sp, height, width));
     PhaseClock clk{h, false}, sorclk{h, false};
     PAPOF_TRY(smooth_flow(h, f1, f2, w, du, dv, height, width, c, alpha, n_outer, n_sor, omega, sor_mode, B, clk,
                           sorclk));
@@ -913,6 +923,7 @@ int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_m
     for (int k = 0; k < 6; k++) planes[k] = S.up_planar(host.data() + k * np, height, width, 1);
     SorPlanes sp{};
     PAPOF_TRY(alloc_sor_planes(S, height, width, sor_mode, sp));
+    PAPOF_TRY(sor_reset_planes(h, sp, height, width));
     PAPOF_TRY(sor_prep(h, planes[0], planes[1], planes[2], planes[3], planes[4], planes[5], height, width, 0.012, 1.8,
                        sp));
     PAPOF_TRY(sor_solve(h, sp, height, width, 0.012, 1.8, n_sor, sor_mode));  // warm-up

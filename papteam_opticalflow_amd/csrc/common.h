@@ -70,16 +70,22 @@ struct Arena {
     void release(size_t m) { off = m; }
 };
 
+constexpr int kSorGroup = 4;   // steps per register-prefetched group of the exact-order SOR kernel
+
 struct SkewDims {
     int nb;     // bands of 64 rows
-    int ns;     // steps per task = W + 63
-    size_t n;   // doubles per skewed plane
+    int ns;     // steps per task that touch real cells = W + 63
+    int nsp;    // band stride in skew positions: ns rounded up to a pair of groups, plus one spare pair, so the
+                // kernel may run / prefetch whole groups past ns without leaving its own band
+    size_t n;   // doubles per skewed plane (all positions that are not real cells must hold 0.0)
 };
 inline SkewDims skew_dims(int h, int w) {
     SkewDims d;
+    const int pair = 2 * kSorGroup;
     d.nb = (h + kLanes - 1) / kLanes;
     d.ns = w + kLanes - 1;
-    d.n = (size_t)d.nb * d.ns * kLanes;
+    d.nsp = (d.ns + pair - 1) / pair * pair + pair;
+    d.n = (size_t)d.nb * d.nsp * kLanes;
     return d;
 }
 
@@ -103,6 +109,8 @@ struct papof_handle {
     std::vector<hipEvent_t> events;
     size_t events_used = 0;
     int cu_count = 0;
+    bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
+    int sor_chunk = 32;              // steps between progress-counter publications of the exact-order SOR
 };
 
 namespace papof {
@@ -139,5 +147,7 @@ Taps central3_taps();
 // ---- sor.hip ----
 int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor, int mode);
 int sor_check(papof_handle* h);  // after a stream sync: PAPOF_ETIMEOUT if a device-side wait expired
+int sor_reset_planes(papof_handle* h, const SorPlanes& sp, int H, int W);  // zero the padding (once per level)
+int sor_probe_dpp(papof_handle* h);  // sets h->use_dpp after checking the cross-lane DPP semantics on the device
 
 }  // namespace papof

@@ -213,10 +213,10 @@ __global__ void k_phi(const double* __restrict__ u, const double* __restrict__ v
 
 // index of cell (i, j) in an SOR operand plane
 template <bool SKEW>
-__device__ __forceinline__ size_t sor_index(int i, int j, int W, int ns) {
+__device__ __forceinline__ size_t sor_index(int i, int j, int W, int nsp) {
     if (SKEW) {
         const int b = i >> 6, r = i & 63;
-        return ((size_t)b * ns + (j + r)) * kLanes + r;
+        return ((size_t)b * nsp + (j + r)) * kLanes + r;
     }
     return (size_t)i * W + j;
 }
@@ -571,7 +571,7 @@ int compute_phi(papof_handle* h, const double* u, const double* v, double* phi, 
 int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,
                     const double* v, int H, int W, int planes, double alpha, double omega, const SorPlanes& out,
                     double* opt_imdx2, double* opt_imdy2) {
-    const int ns = skew_dims(H, W).ns;
+    const int ns = skew_dims(H, W).nsp;
     if (out.skew)
         hipLaunchKernelGGL(k_assemble<true>, grid2d(W, H), dim3(BX, BY), 0, h->stream, blend, imdt, phi, u, v, H, W,
                            planes, alpha, omega, ns, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2, opt_imdx2,
@@ -592,7 +592,7 @@ int laplacian(papof_handle* h, const double* in, const double* weight, double* o
 
 int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, const double* im1,
                     const double* im2, double* warp, int H, int W, int planes) {
-    const int ns = skew_dims(H, W).ns;
+    const int ns = skew_dims(H, W).nsp;
     if (sp.skew)
         hipLaunchKernelGGL(k_update_warp<true>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, u, v, im1,
                            im2, warp, H, W, planes, ns);
@@ -613,7 +613,7 @@ int bicubic_warp(papof_handle* h, const double* im1, const double* im2, const do
 
 int sor_prep(papof_handle* h, const double* phi, const double* imdxy, const double* imdx2, const double* imdy2,
              const double* rhs1, const double* rhs2, int H, int W, double alpha, double omega, const SorPlanes& out) {
-    const int ns = skew_dims(H, W).ns;
+    const int ns = skew_dims(H, W).nsp;
     if (out.skew)
         hipLaunchKernelGGL(k_sor_prep<true>, grid2d(W, H), dim3(BX, BY), 0, h->stream, phi, imdxy, imdx2, imdy2,
                            rhs1, rhs2, H, W, alpha, omega, ns, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2);
@@ -625,7 +625,7 @@ int sor_prep(papof_handle* h, const double* phi, const double* imdxy, const doub
 }
 
 int sor_unpack(papof_handle* h, const SorPlanes& sp, double* du, double* dv, int H, int W) {
-    const int ns = skew_dims(H, W).ns;
+    const int ns = skew_dims(H, W).nsp;
     if (sp.skew)
         hipLaunchKernelGGL(k_sor_unpack<true>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, du, dv, H, W,
                            ns);

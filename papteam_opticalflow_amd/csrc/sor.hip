@@ -40,6 +40,10 @@
 //
 // PAPOF_SOR_REDBLACK / PAPOF_SOR_JACOBI -- one launch per half-sweep / sweep on row-major planes;
 //   throughput and correctness-gate modes whose results differ from the reference's order.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
 
 namespace papof {
@@ -53,7 +57,7 @@ struct ExactArgs {
     double *du, *dv;
     unsigned* prog;   // [n_sor][nb]
     unsigned* abort;  // one word
-    int H, W, nb, ns, n_sor, chunk;
+    int H, W, nb, ns, nsp, n_sor, chunk;
     double nalpha, om1;
 };
 
@@ -81,115 +85,232 @@ __device__ __forceinline__ bool wait_ge(unsigned* p, unsigned need, unsigned* ab
     return true;
 }
 
+// Cross-lane move of one fp64 value by one lane, with the wave-edge lane taking `edge` instead:
+//   from_above(edge, x): lane r <- x of lane r-1 ; lane 0  <- its own `edge`
+//   from_below(edge, x): lane r <- x of lane r+1 ; lane 63 <- its own `edge`
+// DPP wave_shr:1 / wave_shl:1 (GFX9 full-wavefront shifts, dpp_ctrl 0x138 / 0x130; a lane without a source keeps
+// the `old` operand when bound_ctrl = 0) when the start-up probe verified that behaviour on this device,
+// else ds_bpermute + select.
+template <bool DPP>
+__device__ __forceinline__ double from_above(double edge, double x, bool is0) {
+    if (DPP) {
+        int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(x), 0x138, 0xf, 0xf, false);
+        int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(x), 0x138, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
+    const double y = __shfl_up(x, 1);
+    return is0 ? edge : y;
+}
+template <bool DPP>
+__device__ __forceinline__ double from_below(double edge, double x, bool is63) {
+    if (DPP) {
+        int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(x), 0x130, 0xf, 0xf, false);
+        int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(x), 0x130, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
+    const double y = __shfl_down(x, 1);
+    return is63 ? edge : y;
+}
+
+__global__ void k_xlane_probe(int* out) {  // out[0..63] = from_above, out[64..127] = from_below (DPP forms)
+    const int lane = threadIdx.x;
+    const double v = (double)(lane + 1), edge = (double)(1000 + lane);
+    out[lane] = (int)from_above<true>(edge, v, lane == 0);
+    out[64 + lane] = (int)from_below<true>(edge, v, lane == 63);
+}
+
+constexpr int U = kSorGroup;
+
+// Operands of U consecutive steps, prefetched into registers one group ahead of their use.
+struct Group {
+    double phi[U], xy[U], a1[U], a2[U], b1[U], b2[U];  // this lane's cell (r, s - r)
+    double duR[U], dvR[U];                             // right-old = skew position s + 1, previous sweep
+    double hu[U], hv[U], hp[U];                        // halo: lane 0 <- row above (du, dv, phi); lane 63 <- row below
+};
+
+struct Lane {  // per-task constants
+    unsigned lane;       // 0..63
+    unsigned band;       // element offset of (this band, position 0, lane 0) in a plane -- wave-uniform
+    unsigned up_src;     // element offset of (band above, position 63, lane 63)         -- wave-uniform
+    unsigned dn_src;     // element offset of (band below, position -63, lane 0)         -- wave-uniform (may wrap)
+    unsigned zero_src;   // element offset of a padding cell of this band (always 0.0)    -- wave-uniform
+    bool is0, is63, prev, up_any, dn_any;
+    int W;
+};
+
+// All addresses are (uniform plane pointer advanced by a uniform element offset) + lane: scalar address
+// arithmetic and one constant VGPR offset, so the vector ALU is left to the fp64 work.
+__device__ __forceinline__ void load_group(const ExactArgs& A, const Lane& L, int sg, Group& g) {
+    const unsigned base = L.band + (unsigned)sg * kLanes;  // wave-uniform
+    const double* const pphi = A.phi + base;
+    const double* const pxy = A.xy + base;
+    const double* const pa1 = A.a1 + base;
+    const double* const pa2 = A.a2 + base;
+    const double* const pb1 = A.b1 + base;
+    const double* const pb2 = A.b2 + base;
+    const double* const pdu = A.du + base + kLanes;  // right-old: next skew position
+    const double* const pdv = A.dv + base + kLanes;
+#pragma unroll
+    for (int t = 0; t < U; t++) {
+        const unsigned o = (unsigned)t * kLanes + L.lane;
+        g.phi[t] = pphi[o];
+        g.xy[t] = pxy[o];
+        g.a1[t] = pa1[o];
+        g.a2[t] = pa2[o];
+        g.b1[t] = pb1[o];
+        g.b2[t] = pb2[o];
+        double r0 = 0.0, r1 = 0.0;
+        if (L.prev) {  // wave-uniform
+            r0 = ld_agent(pdu + o);
+            r1 = ld_agent(pdv + o);
+        }
+        g.duR[t] = r0;
+        g.dvR[t] = r1;
+        // halo: row 63 of the band above holds column s at its skew position s + 63 (lane 63);
+        //       row 0 of the band below holds column s - 63 at its skew position s - 63 (lane 0).
+        // A source that does not exist is redirected to a padding cell, which always reads 0.0.
+        const int s = sg + t;
+        const bool up_ok = L.up_any && s < L.W;                                    // wave-uniform
+        const bool dn_ok = L.dn_any && s >= kLanes - 1 && s - (kLanes - 1) < L.W;  // wave-uniform
+        const unsigned qu = up_ok ? L.up_src + (unsigned)s * kLanes : L.zero_src;  // scalar selects
+        const unsigned qd = dn_ok ? L.dn_src + (unsigned)s * kLanes : L.zero_src;
+        const unsigned q = L.is63 ? qd : qu;
+        g.hu[t] = ld_agent(A.du + q);
+        g.hv[t] = ld_agent(A.dv + q);
+        g.hp[t] = A.phi[q];
+    }
+}
+
+struct State {
+    double duL, dvL, phiL, duC, dvC;
+};
+
+template <bool DPP>
+__device__ __forceinline__ void compute_group(const ExactArgs& A, const Lane& L, int sg, const Group& g, State& S) {
+    const double nalpha = A.nalpha, om1 = A.om1;
+    const unsigned base = L.band + (unsigned)sg * kLanes;  // wave-uniform
+    double* const pdu = A.du + base;
+    double* const pdv = A.dv + base;
+#pragma unroll
+    for (int t = 0; t < U; t++) {
+        const unsigned o = (unsigned)t * kLanes + L.lane;
+        const double phiC = g.phi[t], duR = g.duR[t], dvR = g.dvR[t];
+        const double duU = from_above<DPP>(g.hu[t], S.duL, L.is0);
+        const double dvU = from_above<DPP>(g.hv[t], S.dvL, L.is0);
+        const double phiU = from_above<DPP>(g.hp[t], S.phiL, L.is0);
+        const double duD = from_below<DPP>(g.hu[t], duR, L.is63);
+        const double dvD = from_below<DPP>(g.hv[t], dvR, L.is63);
+        // Every operand that does not exist (image border, padding, first sweep) is an exact 0.0 here, so the
+        // reference's conditional terms (src/OpticalFlow.cpp:468-495) reduce to adding +-0 in the same order.
+        double s1 = S.phiL * S.duL;
+        double s2 = S.phiL * S.dvL;
+        s1 += phiC * duR;
+        s2 += phiC * dvR;
+        s1 += phiU * duU;
+        s2 += phiU * dvU;
+        s1 += phiC * duD;
+        s2 += phiC * dvD;
+        s1 *= nalpha;
+        s2 *= nalpha;
+        s1 += g.xy[t] * S.dvC;
+        const double duN = om1 * S.duC + g.a1[t] * (g.b1[t] - s1);
+        s2 += g.xy[t] * duN;
+        const double dvN = om1 * S.dvC + g.a2[t] * (g.b2[t] - s2);
+        st_agent(pdu + o, duN);  // padding cells compute and store an exact (+-)0
+        st_agent(pdv + o, dvN);
+        S.duL = duN;
+        S.dvL = dvN;
+        S.phiL = phiC;
+        S.duC = duR;
+        S.dvC = dvR;
+    }
+}
+
+// Wait until the three producers of this task have published enough progress for steps [.., s1).
+__device__ __forceinline__ bool wait_chunk(const ExactArgs& A, unsigned* p_own, unsigned* p_up, unsigned* p_dn,
+                                           bool prev, bool has_up, bool has_dn, int s1) {
+    const int ns = A.ns;
+    const unsigned need_own = (unsigned)min(ns, s1 + 1);
+    const unsigned need_up = (unsigned)min(ns, s1 + 63);
+    const unsigned need_dn = (unsigned)min(ns, max(0, s1 - 63));
+    unsigned spins = 0;
+    for (;;) {
+        // the three polls are issued together; a missing producer is polled on a satisfied dummy
+        const unsigned a = prev ? __hip_atomic_load(p_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need_own;
+        const unsigned b = has_up ? __hip_atomic_load(p_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need_up;
+        const unsigned c =
+            (prev && has_dn) ? __hip_atomic_load(p_dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need_dn;
+        if (a >= need_own && b >= need_up && c >= need_dn) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > kSpinLimit) {
+                __hip_atomic_store(A.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+}
+
+template <bool DPP>
 __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     const int lane = threadIdx.x;
     const int task = blockIdx.x;
     const int k = task / A.nb, b = task - k * A.nb;
-    const int row = b * kLanes + lane;
-    const bool rowok = row < A.H;
-    const int W = A.W, ns = A.ns;
-    const size_t band = (size_t)b * ns * kLanes + lane;  // + s*64 -> this lane's element at step s
+    const int ns = A.ns, nsp = A.nsp;
     const bool has_up = b > 0, has_dn = (b + 1 < A.nb), prev = k > 0;
-    // adjacent-band halo sources: row 63 of band b-1 at column j sits at skew position j+63, lane 63;
-    // row 0 of band b+1 at column j at skew position j, lane 0.
-    const size_t up_base = ((size_t)(b - 1) * ns + 63) * kLanes + 63;
-    const size_t dn_base = (size_t)(b + 1) * ns * kLanes;
+    Lane L;
+    L.lane = (unsigned)lane;
+    L.band = (unsigned)b * (unsigned)nsp * kLanes;
+    L.is0 = lane == 0;
+    L.is63 = lane == kLanes - 1;
+    L.prev = prev;
+    L.up_any = has_up;
+    L.dn_any = prev && has_dn;
+    L.W = A.W;
+    // (band above, position s + 63, lane 63) and (band below, position s - 63, lane 0), relative to step 0;
+    // the unsigned wrap of the unused / early ones is harmless: they are only dereferenced when *_ok holds.
+    L.up_src = ((unsigned)(b - 1) * (unsigned)nsp + (kLanes - 1)) * kLanes + (kLanes - 1);
+    L.dn_src = ((unsigned)(b + 1) * (unsigned)nsp - (kLanes - 1)) * kLanes;
+    L.zero_src = L.band + (unsigned)(nsp - 1) * kLanes;  // last spare position of this band: never a real cell
     unsigned* const my_prog = A.prog + (size_t)k * A.nb + b;
     unsigned* const p_own = A.prog + (size_t)(k - 1) * A.nb + b;
     unsigned* const p_up = A.prog + (size_t)k * A.nb + (b - 1);
     unsigned* const p_dn = A.prog + (size_t)(k - 1) * A.nb + (b + 1);
-    const double nalpha = A.nalpha, om1 = A.om1;
-    const bool top_row = row == 0, last_row = row >= A.H - 1;
 
-    double duL = 0.0, dvL = 0.0, phiL = 0.0, duC = 0.0, dvC = 0.0;
+    const int chunk = A.chunk;                        // multiple of 2U
+    const int nsteps = (ns + 2 * U - 1) / (2 * U) * (2 * U);  // whole pairs of groups; <= nsp - 2U
+    State S{0.0, 0.0, 0.0, 0.0, 0.0};
+    Group ga, gb;
 
-    for (int s0 = 0; s0 < ns; s0 += A.chunk) {
-        const int s1 = min(ns, s0 + A.chunk);
-        bool ok = true;
-        if (prev) ok = ok && wait_ge(p_own, (unsigned)min(ns, s1 + 1), A.abort);
-        if (ok && has_up) ok = wait_ge(p_up, (unsigned)min(ns, s1 + 63), A.abort);
-        if (ok && prev && has_dn) ok = wait_ge(p_dn, (unsigned)min(ns, max(0, s1 - 63)), A.abort);
-        if (!ok) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler-only: keep the loads below the polls
-
-        if (s0 == 0 && prev && lane == 0) {  // centre of the first cell of row 64b (skew position 0)
-            duC = ld_agent(A.du + band);
-            dvC = ld_agent(A.dv + band);
+    if (!wait_chunk(A, p_own, p_up, p_dn, prev, has_up, has_dn, min(ns, chunk))) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler-only: keep the loads below the polls
+    if (prev) {  // centre of the first cell (skew position 0: a real cell for lane 0, padding = 0 for the others)
+        S.duC = ld_agent(A.du + L.band + L.lane);
+        S.dvC = ld_agent(A.dv + L.band + L.lane);
+    }
+    load_group(A, L, 0, ga);
+    for (int sg = 0; sg < nsteps; sg += 2 * U) {
+        // ---- group A computes while group B's operands are in flight ----
+        load_group(A, L, sg + U, gb);
+        compute_group<DPP>(A, L, sg, ga, S);
+        // ---- group B computes while the next pair's first group is in flight ----
+        const int nxt = sg + 2 * U;
+        const bool boundary = (nxt % chunk) == 0 || nxt >= nsteps;
+        if (nxt < nsteps) {
+            if (boundary) {
+                if (!wait_chunk(A, p_own, p_up, p_dn, prev, has_up, has_dn, min(ns, nxt + chunk))) return;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            load_group(A, L, nxt, ga);
         }
-        for (int s = s0; s < s1; ++s) {
-            const int j = s - lane;
-            const bool valid = rowok && j >= 0 && j < W;
-            const bool rvalid = rowok && j + 1 >= 0 && j + 1 < W;
-            const size_t e = band + (size_t)s * kLanes;
-            double phiC = 0.0, xy = 0.0, a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
-            if (valid) {
-                phiC = A.phi[e];
-                xy = A.xy[e];
-                a1 = A.a1[e];
-                a2 = A.a2[e];
-                b1 = A.b1[e];
-                b2 = A.b2[e];
-            }
-            double duR = 0.0, dvR = 0.0;
-            if (prev && rvalid) {
-                duR = ld_agent(A.du + e + kLanes);
-                dvR = ld_agent(A.dv + e + kLanes);
-            }
-            // cross-lane neighbours
-            double duU = __shfl_up(duL, 1), dvU = __shfl_up(dvL, 1), phiU = __shfl_up(phiL, 1);
-            double duD = __shfl_down(duR, 1), dvD = __shfl_down(dvR, 1);
-            if (lane == 0) {
-                duU = dvU = phiU = 0.0;
-                if (has_up && s < W) {  // column j = s of the row above
-                    const size_t q = up_base + (size_t)s * kLanes;
-                    duU = ld_agent(A.du + q);
-                    dvU = ld_agent(A.dv + q);
-                    phiU = A.phi[q];
-                }
-            }
-            if (lane == kLanes - 1) {
-                duD = dvD = 0.0;
-                const int j63 = s - (kLanes - 1);
-                if (prev && has_dn && j63 >= 0 && j63 < W) {
-                    const size_t q = dn_base + (size_t)j63 * kLanes;
-                    duD = ld_agent(A.du + q);
-                    dvD = ld_agent(A.dv + q);
-                }
-            }
-            const double wL = phiL;
-            const double wR = (j < W - 1) ? phiC : 0.0;
-            const double wU = top_row ? 0.0 : phiU;
-            const double wD = last_row ? 0.0 : phiC;
-            double s1v = wL * duL;
-            double s2v = wL * dvL;
-            s1v += wR * duR;
-            s2v += wR * dvR;
-            s1v += wU * duU;
-            s2v += wU * dvU;
-            s1v += wD * duD;
-            s2v += wD * dvD;
-            s1v *= nalpha;
-            s2v *= nalpha;
-            s1v += xy * dvC;
-            double duN = om1 * duC + a1 * (b1 - s1v);
-            s2v += xy * duN;
-            double dvN = om1 * dvC + a2 * (b2 - s2v);
-            if (!valid) {
-                duN = 0.0;
-                dvN = 0.0;
-            } else {
-                st_agent(A.du + e, duN);
-                st_agent(A.dv + e, dvN);
-            }
-            duL = duN;
-            dvL = dvN;
-            phiL = phiC;
-            duC = duR;
-            dvC = dvR;
+        compute_group<DPP>(A, L, sg + U, gb, S);
+        if (boundary) {
+            // publish: every store of this wave has left the CU before the counter moves (guide G16/R1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                __hip_atomic_store(my_prog, (unsigned)min(ns, nxt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // publish: every store of this wave has left the CU before the counter moves (guide G16/R1)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(my_prog, (unsigned)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -262,6 +383,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
     if (mode == PAPOF_SOR_EXACT) {
         if (!sp.skew) return PAPOF_EINVAL;
         const SkewDims sd = skew_dims(H, W);
+        if ((sd.n + kLanes) * sizeof(double) >= (size_t(1) << 32)) return PAPOF_EINVAL;  // 32-bit element offsets
         const size_t words = (size_t)sd.nb * n_sor + 4;
         if (words > h->sync_cap) {
             PAPOF_HIP(hipStreamSynchronize(h->stream));
@@ -292,11 +414,15 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.W = W;
         A.nb = sd.nb;
         A.ns = sd.ns;
+        A.nsp = sd.nsp;
         A.n_sor = n_sor;
-        A.chunk = 16;
+        A.chunk = std::max(2 * U, h->sor_chunk / (2 * U) * (2 * U));
         A.nalpha = nalpha;
         A.om1 = om1;
-        hipLaunchKernelGGL(k_sor_exact, dim3(sd.nb * n_sor), dim3(kLanes), 0, h->stream, A);
+        if (h->use_dpp)
+            hipLaunchKernelGGL(k_sor_exact<true>, dim3(sd.nb * n_sor), dim3(kLanes), 0, h->stream, A);
+        else
+            hipLaunchKernelGGL(k_sor_exact<false>, dim3(sd.nb * n_sor), dim3(kLanes), 0, h->stream, A);
         PAPOF_HIP(hipGetLastError());
         return PAPOF_OK;
     }
@@ -335,6 +461,42 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         return PAPOF_OK;
     }
     return PAPOF_EINVAL;
+}
+
+// All skew positions that are not real cells must read as 0.0 (the kernel relies on it instead of predicates).
+// Real cells are rewritten by the assembly kernel each outer iteration and padding is only ever written with
+// zeros, so one memset per (level, plane) suffices.
+int sor_reset_planes(papof_handle* h, const SorPlanes& sp, int H, int W) {
+    if (!sp.skew) return PAPOF_OK;
+    const size_t bytes = (skew_dims(H, W).n + kLanes) * sizeof(double);
+    double* planes[8] = {sp.phi, sp.xy, sp.a1, sp.a2, sp.b1, sp.b2, sp.du, sp.dv};
+    for (double* p : planes) PAPOF_HIP(hipMemsetAsync(p, 0, bytes, h->stream));
+    return PAPOF_OK;
+}
+
+int sor_probe_dpp(papof_handle* h) {
+    h->use_dpp = false;
+    int* d = nullptr;
+    PAPOF_HIP(hipMalloc((void**)&d, 128 * sizeof(int)));
+    PAPOF_HIP(hipMemsetAsync(d, 0xff, 128 * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_xlane_probe, dim3(1), dim3(kLanes), 0, h->stream, d);
+    int host[128];
+    hipError_t e = hipMemcpyAsync(host, d, sizeof host, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    if (e != hipSuccess) {
+        set_last_error("dpp probe", e, __FILE__, __LINE__);
+        return PAPOF_EDEVICE;
+    }
+    bool ok = true;
+    for (int l = 1; l < 64; l++) ok = ok && host[l] == l;             // lane l sees lane l-1 (value l-1+1)
+    for (int l = 0; l < 63; l++) ok = ok && host[64 + l] == l + 2;    // lane l sees lane l+1 (value l+1+1)
+    ok = ok && host[0] == 1000 && host[127] == 1063;                  // edge lanes keep their own `edge` operand
+    h->use_dpp = ok;
+    if (const char* s = std::getenv("PAPOF_SOR_XLANE")) {
+        if (std::strcmp(s, "shfl") == 0) h->use_dpp = false;
+    }
+    return PAPOF_OK;
 }
 
 int sor_check(papof_handle* h) {
