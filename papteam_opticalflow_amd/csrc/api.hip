@@ -187,22 +187,7 @@ int alloc_solve_buffers(Arena& A, int H, int W, int fc, int mode, SolveBuffers& 
     B.blend = A.f64(np * fc);
     B.imdt = A.f64(np * fc);
     B.phi = A.f64(np);
-    const bool skew = mode == PAPOF_SOR_EXACT;
-    const size_t n = skew ? skew_dims(H, W).n + kLanes : np;
-    B.sp.skew = skew;
-    B.sp.phi = A.f64(n);
-    B.sp.xy = A.f64(n);
-    B.sp.a1 = A.f64(n);
-    B.sp.a2 = A.f64(n);
-    B.sp.b1 = A.f64(n);
-    B.sp.b2 = A.f64(n);
-    B.sp.du = A.f64(n);
-    B.sp.dv = A.f64(n);
-    B.sp.du2 = B.sp.dv2 = nullptr;
-    if (mode == PAPOF_SOR_JACOBI) {
-        B.sp.du2 = A.f64(n);
-        B.sp.dv2 = A.f64(n);
-    }
+    PAPOF_TRY(sor_alloc_planes(A, H, W, mode, B.sp));
     return A.overflow ? PAPOF_ENOMEM : PAPOF_OK;
 }
 
@@ -421,7 +406,7 @@ int papof_create(int device, papof_handle** out) {
         delete h;
         return PAPOF_ENODEVICE;
     }
-    if (const char* cs = std::getenv("PAPOF_SOR_CHUNK")) h->sor_chunk = std::max(8, std::atoi(cs));
+    if (const char* cs = std::getenv("PAPOF_SOR_DEPTH")) h->sor_depth = std::max(8, std::atoi(cs));
     int rc = sor_probe_dpp(h);
     if (rc != PAPOF_OK) {
         papof_destroy(h);
@@ -798,22 +783,8 @@ int papof_stage_laplacian(papof_handle* h, const double* in, const double* weigh
 
 namespace {
 int alloc_sor_planes(Scope& S, int H, int W, int mode, SorPlanes& sp) {
-    const bool skew = mode == PAPOF_SOR_EXACT;
-    const size_t n = skew ? skew_dims(H, W).n + kLanes : (size_t)H * W;
-    sp.skew = skew;
-    sp.phi = S.dev(n);
-    sp.xy = S.dev(n);
-    sp.a1 = S.dev(n);
-    sp.a2 = S.dev(n);
-    sp.b1 = S.dev(n);
-    sp.b2 = S.dev(n);
-    sp.du = S.dev(n);
-    sp.dv = S.dev(n);
-    sp.du2 = sp.dv2 = nullptr;
-    if (mode == PAPOF_SOR_JACOBI) {
-        sp.du2 = S.dev(n);
-        sp.dv2 = S.dev(n);
-    }
+    int rc = sor_alloc_planes(S.h->arena, H, W, mode, sp);
+    if (rc != PAPOF_OK) S.rc = rc;
     return S.rc;
 }
 }  // namespace

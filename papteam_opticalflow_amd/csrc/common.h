@@ -70,26 +70,29 @@ struct Arena {
     void release(size_t m) { off = m; }
 };
 
-constexpr int kSorGroup = 4;   // steps per register-prefetched group of the exact-order SOR kernel
+constexpr int kSorMaxDepth = 32;  // largest software-pipeline depth (steps) of the exact-order SOR kernel
 
 struct SkewDims {
     int nb;     // bands of 64 rows
     int ns;     // steps per task that touch real cells = W + 63
-    int nsp;    // band stride in skew positions: ns rounded up to a pair of groups, plus one spare pair, so the
-                // kernel may run / prefetch whole groups past ns without leaving its own band
+    int nsp;    // band stride in skew positions: ns rounded up plus two pipeline depths of spare positions, so the
+                // kernel may run / prefetch whole iterations past ns without leaving its own band
     size_t n;   // doubles per skewed plane (all positions that are not real cells must hold 0.0)
 };
 inline SkewDims skew_dims(int h, int w) {
     SkewDims d;
-    const int pair = 2 * kSorGroup;
     d.nb = (h + kLanes - 1) / kLanes;
     d.ns = w + kLanes - 1;
-    d.nsp = (d.ns + pair - 1) / pair * pair + pair;
+    d.nsp = (d.ns + kSorMaxDepth - 1) / kSorMaxDepth * kSorMaxDepth + 2 * kSorMaxDepth;
     d.n = (size_t)d.nb * d.nsp * kLanes;
     return d;
 }
 
-// SOR operands of one solve.  `skew` selects the layout of all eight planes.
+// SOR operands of one solve.  `skew` selects the layout of all eight planes:
+//   row-major modes: eight dense H*W planes;
+//   skew (exact-order) mode: four PAIRED planes of 16-byte cells -- (phi,xy) (a1,a2) (b1,b2) (du,dv) -- so that
+//   every access of the solver is one 16-byte-per-lane, 1-KiB-per-wave instruction.  The eight pointers then
+//   alias the pairs with element stride 2: xy = phi + 1, a2 = a1 + 1, b2 = b1 + 1, dv = du + 1.
 struct SorPlanes {
     double *phi, *xy, *a1, *a2, *b1, *b2;  // weights, imdxy, omega/diag_u, omega/diag_v, rhs_u, rhs_v
     double *du, *dv;                       // unknowns (written from zero; no initialisation needed)
@@ -110,7 +113,7 @@ struct papof_handle {
     size_t events_used = 0;
     int cu_count = 0;
     bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
-    int sor_chunk = 32;              // steps between progress-counter publications of the exact-order SOR
+    int sor_depth = 8;               // software-pipeline depth R (steps) of the exact-order SOR kernel
 };
 
 namespace papof {
@@ -148,6 +151,7 @@ Taps central3_taps();
 int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor, int mode);
 int sor_check(papof_handle* h);  // after a stream sync: PAPOF_ETIMEOUT if a device-side wait expired
 int sor_reset_planes(papof_handle* h, const SorPlanes& sp, int H, int W);  // zero the padding (once per level)
+int sor_alloc_planes(Arena& A, int H, int W, int mode, SorPlanes& sp);      // carve the operands of one solve
 int sor_probe_dpp(papof_handle* h);  // sets h->use_dpp after checking the cross-lane DPP semantics on the device
 
 }  // namespace papof

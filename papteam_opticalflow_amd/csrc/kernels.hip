@@ -214,9 +214,9 @@ __global__ void k_phi(const double* __restrict__ u, const double* __restrict__ v
 // index of cell (i, j) in an SOR operand plane
 template <bool SKEW>
 __device__ __forceinline__ size_t sor_index(int i, int j, int W, int nsp) {
-    if (SKEW) {
+    if (SKEW) {  // paired planes: (phi,xy) (a1,a2) (b1,b2) (du,dv) are interleaved, see common.h
         const int b = i >> 6, r = i & 63;
-        return ((size_t)b * nsp + (j + r)) * kLanes + r;
+        return 2 * (((size_t)b * nsp + (j + r)) * kLanes + r);
     }
     return (size_t)i * W + j;
 }

@@ -50,6 +50,7 @@ namespace papof {
 
 namespace {
 
+constexpr int kProgStride = 32;  // unsigneds between progress counters = one 128-byte cache line each
 constexpr unsigned kSpinLimit = 4u << 20;  // bounded wait: ~4M polls (seconds), then abort
 
 struct ExactArgs {
@@ -119,128 +120,178 @@ __global__ void k_xlane_probe(int* out) {  // out[0..63] = from_above, out[64..1
     out[64 + lane] = (int)from_below<true>(edge, v, lane == 63);
 }
 
-constexpr int U = kSorGroup;
+// ---- 16-byte accesses through buffer descriptors (one SGPR quad per paired plane) -------------------------
+// voffset = lane * 16 (a constant VGPR), soffset = wave-uniform byte offset of the step: all address arithmetic is
+// scalar.  aux = 16 sets `sc1` (agent-coherent: write-through stores, L1-bypassing loads) on the du/dv plane;
+// out-of-range offsets would read 0 / drop the store (num_records = plane size), never fault.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct D2 {
+    double x, y;
+};
+__device__ __forceinline__ D2 as_d2(u32x4 v) {
+    D2 r;
+    __builtin_memcpy(&r, &v, sizeof r);
+    return r;
+}
+__device__ __forceinline__ u32x4 as_u4(double x, double y) {
+    D2 d{x, y};
+    u32x4 r;
+    __builtin_memcpy(&r, &d, sizeof r);
+    return r;
+}
+constexpr int kAuxPlain = 0, kAuxSc1 = 16;
 
-// Operands of U consecutive steps, prefetched into registers one group ahead of their use.
-struct Group {
-    double phi[U], xy[U], a1[U], a2[U], b1[U], b2[U];  // this lane's cell (r, s - r)
-    double duR[U], dvR[U];                             // right-old = skew position s + 1, previous sweep
-    double hu[U], hv[U], hp[U];                        // halo: lane 0 <- row above (du, dv, phi); lane 63 <- row below
+// Operands of R consecutive steps held in registers: slot t of the running iteration is consumed by step
+// i*R + t and immediately refilled with the operands of step (i+1)*R + t, i.e. every global load is issued
+// R steps before its use, so the latency of the write-through du/dv traffic and of the coefficient streams is
+// hidden behind R steps of arithmetic instead of being paid once per step.  A step costs 4 loads + 1 store of
+// 1 KiB each; R <= 10 keeps the loads in flight within the 6-bit vmcnt range (63) of gfx9.
+template <int R>
+struct Slots {
+    u32x4 pa[R], pb[R], pc[R];  // (phi, xy) (a1, a2) (b1, b2) of this lane's cell (r, s - r)
+    u32x4 pd[R];                // right-old (du, dv) = skew position s + 1, previous sweep
 };
 
-struct Lane {  // per-task constants
-    unsigned lane;       // 0..63
-    unsigned band;       // element offset of (this band, position 0, lane 0) in a plane -- wave-uniform
-    unsigned up_src;     // element offset of (band above, position 63, lane 63)         -- wave-uniform
-    unsigned dn_src;     // element offset of (band below, position -63, lane 0)         -- wave-uniform (may wrap)
-    unsigned zero_src;   // element offset of a padding cell of this band (always 0.0)    -- wave-uniform
-    bool is0, is63, prev, up_any, dn_any;
-    int W;
+// Halo values of R consecutive steps, one step per lane, rotated by one lane after every step so that the
+// lane that needs them always holds the current step's value:
+//   up block: lane l = row above, column of step base + l        -> lane 0 reads it, block rotates downwards
+//   dn block: lane 63 - l = row below, column of step base + l   -> lane 63 reads it, block rotates upwards
+struct Halo {
+    double up_du, up_dv, up_phi, dn_du, dn_dv;
 };
 
-// All addresses are (uniform plane pointer advanced by a uniform element offset) + lane: scalar address
-// arithmetic and one constant VGPR offset, so the vector ALU is left to the fp64 work.
-__device__ __forceinline__ void load_group(const ExactArgs& A, const Lane& L, int sg, Group& g) {
-    const unsigned base = L.band + (unsigned)sg * kLanes;  // wave-uniform
-    const double* const pphi = A.phi + base;
-    const double* const pxy = A.xy + base;
-    const double* const pa1 = A.a1 + base;
-    const double* const pa2 = A.a2 + base;
-    const double* const pb1 = A.b1 + base;
-    const double* const pb2 = A.b2 + base;
-    const double* const pdu = A.du + base + kLanes;  // right-old: next skew position
-    const double* const pdv = A.dv + base + kLanes;
-#pragma unroll
-    for (int t = 0; t < U; t++) {
-        const unsigned o = (unsigned)t * kLanes + L.lane;
-        g.phi[t] = pphi[o];
-        g.xy[t] = pxy[o];
-        g.a1[t] = pa1[o];
-        g.a2[t] = pa2[o];
-        g.b1[t] = pb1[o];
-        g.b2[t] = pb2[o];
-        double r0 = 0.0, r1 = 0.0;
-        if (L.prev) {  // wave-uniform
-            r0 = ld_agent(pdu + o);
-            r1 = ld_agent(pdv + o);
-        }
-        g.duR[t] = r0;
-        g.dvR[t] = r1;
-        // halo: row 63 of the band above holds column s at its skew position s + 63 (lane 63);
-        //       row 0 of the band below holds column s - 63 at its skew position s - 63 (lane 0).
-        // A source that does not exist is redirected to a padding cell, which always reads 0.0.
-        const int s = sg + t;
-        const bool up_ok = L.up_any && s < L.W;                                    // wave-uniform
-        const bool dn_ok = L.dn_any && s >= kLanes - 1 && s - (kLanes - 1) < L.W;  // wave-uniform
-        const unsigned qu = up_ok ? L.up_src + (unsigned)s * kLanes : L.zero_src;  // scalar selects
-        const unsigned qd = dn_ok ? L.dn_src + (unsigned)s * kLanes : L.zero_src;
-        const unsigned q = L.is63 ? qd : qu;
-        g.hu[t] = ld_agent(A.du + q);
-        g.hv[t] = ld_agent(A.dv + q);
-        g.hp[t] = A.phi[q];
-    }
+struct Task {  // wave-uniform task constants (SGPRs)
+    __amdgpu_buffer_rsrc_t ra, rb, rc, rd;  // descriptors of the four paired planes
+    unsigned band;      // cell offset of (this band, position 0, lane 0)
+    unsigned up_src;    // cell offset of (band above, position 63, lane 63) for step 0
+    unsigned dn_src;    // cell offset of (band below, position -63, lane 0) for step 0 (wraps; guarded)
+    unsigned zero_src;  // cell offset of a cell of this band that is never real: always reads 0.0
+    bool prev, up_any, dn_any;
+    int W, ns;
+};
+
+// Halo block for steps [base, base + R): three loads for the whole wave.
+template <int R>
+__device__ __forceinline__ void load_halo(const Task& T, unsigned lane, int base, Halo& h) {
+    const int su = base + (int)lane;                 // step served by this lane of the up block
+    const int sd = base + (kLanes - 1 - (int)lane);  // step served by this lane of the dn block
+    const bool up_ok = T.up_any && (int)lane < R && su < T.W;
+    const bool dn_ok = T.dn_any && (kLanes - 1 - (int)lane) < R && sd >= kLanes - 1 && sd - (kLanes - 1) < T.W;
+    const unsigned qu = (up_ok ? T.up_src + (unsigned)su * kLanes : T.zero_src) * 16u;
+    const unsigned qd = (dn_ok ? T.dn_src + (unsigned)sd * kLanes : T.zero_src) * 16u;
+    const D2 u = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, qu, 0, kAuxSc1));
+    const D2 p = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.ra, qu, 0, kAuxPlain));
+    const D2 d = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, qd, 0, kAuxSc1));
+    h.up_du = u.x;
+    h.up_dv = u.y;
+    h.up_phi = p.x;
+    h.dn_du = d.x;
+    h.dn_dv = d.y;
+}
+
+template <int R, int t>
+__device__ __forceinline__ void load_slot(const Task& T, unsigned lane16, int s, Slots<R>& c) {
+    const unsigned off = (T.band + (unsigned)s * kLanes) * 16u;  // wave-uniform byte offset -> soffset
+    c.pa[t] = __builtin_amdgcn_raw_buffer_load_b128(T.ra, lane16, off, kAuxPlain);
+    c.pb[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rb, lane16, off, kAuxPlain);
+    c.pc[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rc, lane16, off, kAuxPlain);
+    if (T.prev)  // wave-uniform; first sweep: every old value is 0 (src/OpticalFlow.cpp:452-453)
+        c.pd[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rd, lane16, off + kLanes * 16u, kAuxSc1);
+    else
+        c.pd[t] = u32x4{0u, 0u, 0u, 0u};
 }
 
 struct State {
     double duL, dvL, phiL, duC, dvC;
 };
 
-template <bool DPP>
-__device__ __forceinline__ void compute_group(const ExactArgs& A, const Lane& L, int sg, const Group& g, State& S) {
+template <int R, int t, bool DPP>
+__device__ __forceinline__ void step(const ExactArgs& A, const Task& T, unsigned lane16, bool is0, bool is63, int s,
+                                     Slots<R>& c, Halo& h, State& S) {
     const double nalpha = A.nalpha, om1 = A.om1;
-    const unsigned base = L.band + (unsigned)sg * kLanes;  // wave-uniform
-    double* const pdu = A.du + base;
-    double* const pdv = A.dv + base;
-#pragma unroll
-    for (int t = 0; t < U; t++) {
-        const unsigned o = (unsigned)t * kLanes + L.lane;
-        const double phiC = g.phi[t], duR = g.duR[t], dvR = g.dvR[t];
-        const double duU = from_above<DPP>(g.hu[t], S.duL, L.is0);
-        const double dvU = from_above<DPP>(g.hv[t], S.dvL, L.is0);
-        const double phiU = from_above<DPP>(g.hp[t], S.phiL, L.is0);
-        const double duD = from_below<DPP>(g.hu[t], duR, L.is63);
-        const double dvD = from_below<DPP>(g.hv[t], dvR, L.is63);
-        // Every operand that does not exist (image border, padding, first sweep) is an exact 0.0 here, so the
-        // reference's conditional terms (src/OpticalFlow.cpp:468-495) reduce to adding +-0 in the same order.
-        double s1 = S.phiL * S.duL;
-        double s2 = S.phiL * S.dvL;
-        s1 += phiC * duR;
-        s2 += phiC * dvR;
-        s1 += phiU * duU;
-        s2 += phiU * dvU;
-        s1 += phiC * duD;
-        s2 += phiC * dvD;
-        s1 *= nalpha;
-        s2 *= nalpha;
-        s1 += g.xy[t] * S.dvC;
-        const double duN = om1 * S.duC + g.a1[t] * (g.b1[t] - s1);
-        s2 += g.xy[t] * duN;
-        const double dvN = om1 * S.dvC + g.a2[t] * (g.b2[t] - s2);
-        st_agent(pdu + o, duN);  // padding cells compute and store an exact (+-)0
-        st_agent(pdv + o, dvN);
-        S.duL = duN;
-        S.dvL = dvN;
-        S.phiL = phiC;
-        S.duC = duR;
-        S.dvC = dvR;
-    }
+    const D2 pa = as_d2(c.pa[t]), pb = as_d2(c.pb[t]), pc = as_d2(c.pc[t]), pd = as_d2(c.pd[t]);
+    const double phiC = pa.x, xy = pa.y, duR = pd.x, dvR = pd.y;
+    const double duU = from_above<DPP>(h.up_du, S.duL, is0);
+    const double dvU = from_above<DPP>(h.up_dv, S.dvL, is0);
+    const double phiU = from_above<DPP>(h.up_phi, S.phiL, is0);
+    const double duD = from_below<DPP>(h.dn_du, duR, is63);
+    const double dvD = from_below<DPP>(h.dn_dv, dvR, is63);
+    // rotate the halo blocks to the next step (the lane that fell off the edge keeps a stale, unused value)
+    h.up_du = from_below<DPP>(h.up_du, h.up_du, is63);
+    h.up_dv = from_below<DPP>(h.up_dv, h.up_dv, is63);
+    h.up_phi = from_below<DPP>(h.up_phi, h.up_phi, is63);
+    h.dn_du = from_above<DPP>(h.dn_du, h.dn_du, is0);
+    h.dn_dv = from_above<DPP>(h.dn_dv, h.dn_dv, is0);
+    // Every operand that does not exist (image border, padding, first sweep) is an exact 0.0 here, so the
+    // reference's conditional terms (src/OpticalFlow.cpp:468-495) reduce to adding +-0 in the same order.
+    double s1 = S.phiL * S.duL;
+    double s2 = S.phiL * S.dvL;
+    s1 += phiC * duR;
+    s2 += phiC * dvR;
+    s1 += phiU * duU;
+    s2 += phiU * dvU;
+    s1 += phiC * duD;
+    s2 += phiC * dvD;
+    s1 *= nalpha;
+    s2 *= nalpha;
+    s1 += xy * S.dvC;
+    const double duN = om1 * S.duC + pb.x * (pc.x - s1);
+    s2 += xy * duN;
+    const double dvN = om1 * S.dvC + pb.y * (pc.y - s2);
+    const unsigned off = (T.band + (unsigned)s * kLanes) * 16u;
+    // padding cells compute and store an exact (+-)0
+    __builtin_amdgcn_raw_buffer_store_b128(as_u4(duN, dvN), T.rd, lane16, off, kAuxSc1);
+    S.duL = duN;
+    S.dvL = dvN;
+    S.phiL = phiC;
+    S.duC = duR;
+    S.dvC = dvR;
+    asm volatile("" ::: "memory");  // keep this step's store ahead of its refill loads in the instruction stream
+    load_slot<R, t>(T, lane16, s + R, c);  // refill this slot for the step R ahead
 }
 
-// Wait until the three producers of this task have published enough progress for steps [.., s1).
-__device__ __forceinline__ bool wait_chunk(const ExactArgs& A, unsigned* p_own, unsigned* p_up, unsigned* p_dn,
-                                           bool prev, bool has_up, bool has_dn, int s1) {
-    const int ns = A.ns;
-    const unsigned need_own = (unsigned)min(ns, s1 + 1);
-    const unsigned need_up = (unsigned)min(ns, s1 + 63);
-    const unsigned need_dn = (unsigned)min(ns, max(0, s1 - 63));
+template <int R, int t, bool DPP>
+struct Unroll {
+    static __device__ __forceinline__ void run(const ExactArgs& A, const Task& T, unsigned lane16, bool is0,
+                                               bool is63, int s0, Slots<R>& c, Halo& h, State& S) {
+        Unroll<R, t - 1, DPP>::run(A, T, lane16, is0, is63, s0, c, h, S);
+        step<R, t, DPP>(A, T, lane16, is0, is63, s0 + t, c, h, S);
+    }
+    static __device__ __forceinline__ void fill(const Task& T, unsigned lane16, Slots<R>& c) {
+        Unroll<R, t - 1, DPP>::fill(T, lane16, c);
+        load_slot<R, t>(T, lane16, t, c);
+    }
+};
+template <int R, bool DPP>
+struct Unroll<R, -1, DPP> {
+    static __device__ __forceinline__ void run(const ExactArgs&, const Task&, unsigned, bool, bool, int, Slots<R>&,
+                                               Halo&, State&) {}
+    static __device__ __forceinline__ void fill(const Task&, unsigned, Slots<R>&) {}
+};
+
+// Progress of the three producers of a task, polled together (a missing producer reads as "finished").
+struct Polls {
+    unsigned own, up, dn;
+};
+__device__ __forceinline__ Polls poll(unsigned* p_own, unsigned* p_up, unsigned* p_dn, bool prev, bool has_up,
+                                      bool has_dn) {
+    Polls p;
+    p.own = prev ? __hip_atomic_load(p_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
+    p.up = has_up ? __hip_atomic_load(p_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
+    p.dn = (prev && has_dn) ? __hip_atomic_load(p_dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
+    return p;
+}
+// May every load that touches steps < s_end be issued?  (see the dependency table in the file header)
+__device__ __forceinline__ bool covered(const Polls& p, int ns, int s_end) {
+    return p.own >= (unsigned)min(ns, s_end + 1) && p.up >= (unsigned)min(ns, s_end + 63) &&
+           p.dn >= (unsigned)min(ns, max(0, s_end - 63));
+}
+
+// Bounded wave-uniform wait until the producers cover steps < s_end.  false = abort / timeout.
+__device__ __forceinline__ bool wait_covered(const ExactArgs& A, Polls& pl, unsigned* p_own, unsigned* p_up,
+                                             unsigned* p_dn, bool prev, bool has_up, bool has_dn, int s_end) {
     unsigned spins = 0;
-    for (;;) {
-        // the three polls are issued together; a missing producer is polled on a satisfied dummy
-        const unsigned a = prev ? __hip_atomic_load(p_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need_own;
-        const unsigned b = has_up ? __hip_atomic_load(p_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need_up;
-        const unsigned c =
-            (prev && has_dn) ? __hip_atomic_load(p_dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need_dn;
-        if (a >= need_own && b >= need_up && c >= need_dn) return true;
+    while (!covered(pl, A.ns, s_end)) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 255u) == 0u) {
             if (__hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
@@ -249,69 +300,80 @@ __device__ __forceinline__ bool wait_chunk(const ExactArgs& A, unsigned* p_own, 
                 return false;
             }
         }
+        pl = poll(p_own, p_up, p_dn, prev, has_up, has_dn);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler-only: keep the loads below the polls
+    return true;
 }
 
-template <bool DPP>
+template <int R, bool DPP>
 __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
-    const int lane = threadIdx.x;
+    const unsigned lane = threadIdx.x, lane16 = lane * 16u;
     const int task = blockIdx.x;
     const int k = task / A.nb, b = task - k * A.nb;
     const int ns = A.ns, nsp = A.nsp;
     const bool has_up = b > 0, has_dn = (b + 1 < A.nb), prev = k > 0;
-    Lane L;
-    L.lane = (unsigned)lane;
-    L.band = (unsigned)b * (unsigned)nsp * kLanes;
-    L.is0 = lane == 0;
-    L.is63 = lane == kLanes - 1;
-    L.prev = prev;
-    L.up_any = has_up;
-    L.dn_any = prev && has_dn;
-    L.W = A.W;
+    const bool is0 = lane == 0, is63 = lane == kLanes - 1;
+    Task T;
+    const unsigned plane_bytes = (unsigned)(((size_t)A.nb * nsp + 1) * kLanes * 16u);
+    T.ra = __builtin_amdgcn_make_buffer_rsrc((void*)A.phi, 0, plane_bytes, 0x00020000);
+    T.rb = __builtin_amdgcn_make_buffer_rsrc((void*)A.a1, 0, plane_bytes, 0x00020000);
+    T.rc = __builtin_amdgcn_make_buffer_rsrc((void*)A.b1, 0, plane_bytes, 0x00020000);
+    T.rd = __builtin_amdgcn_make_buffer_rsrc((void*)A.du, 0, plane_bytes, 0x00020000);
+    T.band = (unsigned)b * (unsigned)nsp * kLanes;
+    T.prev = prev;
+    T.up_any = has_up;
+    T.dn_any = prev && has_dn;
+    T.W = A.W;
+    T.ns = ns;
     // (band above, position s + 63, lane 63) and (band below, position s - 63, lane 0), relative to step 0;
     // the unsigned wrap of the unused / early ones is harmless: they are only dereferenced when *_ok holds.
-    L.up_src = ((unsigned)(b - 1) * (unsigned)nsp + (kLanes - 1)) * kLanes + (kLanes - 1);
-    L.dn_src = ((unsigned)(b + 1) * (unsigned)nsp - (kLanes - 1)) * kLanes;
-    L.zero_src = L.band + (unsigned)(nsp - 1) * kLanes;  // last spare position of this band: never a real cell
-    unsigned* const my_prog = A.prog + (size_t)k * A.nb + b;
-    unsigned* const p_own = A.prog + (size_t)(k - 1) * A.nb + b;
-    unsigned* const p_up = A.prog + (size_t)k * A.nb + (b - 1);
-    unsigned* const p_dn = A.prog + (size_t)(k - 1) * A.nb + (b + 1);
+    T.up_src = ((unsigned)(b - 1) * (unsigned)nsp + (kLanes - 1)) * kLanes + (kLanes - 1);
+    T.dn_src = ((unsigned)(b + 1) * (unsigned)nsp - (kLanes - 1)) * kLanes;
+    T.zero_src = T.band + (unsigned)(nsp - 1) * kLanes;  // last spare position of this band: never a real cell
+    // one 128-byte line per counter: hundreds of waves publish and poll concurrently, and counters sharing a
+    // line would serialise at the memory side
+    unsigned* const my_prog = A.prog + ((size_t)k * A.nb + b) * kProgStride;
+    unsigned* const p_own = A.prog + ((size_t)(k - 1) * A.nb + b) * kProgStride;
+    unsigned* const p_up = A.prog + ((size_t)k * A.nb + (b - 1)) * kProgStride;
+    unsigned* const p_dn = A.prog + ((size_t)(k - 1) * A.nb + (b + 1)) * kProgStride;
 
-    const int chunk = A.chunk;                        // multiple of 2U
-    const int nsteps = (ns + 2 * U - 1) / (2 * U) * (2 * U);  // whole pairs of groups; <= nsp - 2U
+    const int n_iter = (ns + R - 1) / R;  // steps beyond ns only touch padding (nsp >= n_iter*R + R + 1)
     State S{0.0, 0.0, 0.0, 0.0, 0.0};
-    Group ga, gb;
+    Slots<R> c;
+    Halo h, hn;
 
-    if (!wait_chunk(A, p_own, p_up, p_dn, prev, has_up, has_dn, min(ns, chunk))) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler-only: keep the loads below the polls
+    // Before iteration i every load it issues (slots and halo block of iteration i + 1) must be covered:
+    // producers' progress for steps < (i + 2) * R.  The polls themselves are prefetched one iteration ahead.
+    Polls pl = poll(p_own, p_up, p_dn, prev, has_up, has_dn);
+    if (!wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, 2 * R)) return;
     if (prev) {  // centre of the first cell (skew position 0: a real cell for lane 0, padding = 0 for the others)
-        S.duC = ld_agent(A.du + L.band + L.lane);
-        S.dvC = ld_agent(A.dv + L.band + L.lane);
+        const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, lane16, T.band * 16u, kAuxSc1));
+        S.duC = c0.x;
+        S.dvC = c0.y;
     }
-    load_group(A, L, 0, ga);
-    for (int sg = 0; sg < nsteps; sg += 2 * U) {
-        // ---- group A computes while group B's operands are in flight ----
-        load_group(A, L, sg + U, gb);
-        compute_group<DPP>(A, L, sg, ga, S);
-        // ---- group B computes while the next pair's first group is in flight ----
-        const int nxt = sg + 2 * U;
-        const bool boundary = (nxt % chunk) == 0 || nxt >= nsteps;
-        if (nxt < nsteps) {
-            if (boundary) {
-                if (!wait_chunk(A, p_own, p_up, p_dn, prev, has_up, has_dn, min(ns, nxt + chunk))) return;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            load_group(A, L, nxt, ga);
-        }
-        compute_group<DPP>(A, L, sg + U, gb, S);
-        if (boundary) {
-            // publish: every store of this wave has left the CU before the counter moves (guide G16/R1)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)
-                __hip_atomic_store(my_prog, (unsigned)min(ns, nxt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    load_halo<R>(T, lane, 0, h);
+    Unroll<R, R - 1, DPP>::fill(T, lane16, c);
+
+    for (int i = 0; i < n_iter; ++i) {
+        if (i > 0 && !wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, (i + 2) * R)) return;
+        load_halo<R>(T, lane, (i + 1) * R, hn);                             // halo block of iteration i + 1
+        const Polls pn = poll(p_own, p_up, p_dn, prev, has_up, has_dn);     // poll for iteration i + 1
+        Unroll<R, R - 1, DPP>::run(A, T, lane16, is0, is63, i * R, c, h, S);
+        h = hn;
+        pl = pn;
+        // Lagged publication without draining the memory pipeline: vmcnt retires in issue order, so once the
+        // slot loads issued during iteration i-1 have been consumed (all of them were, just above), every store
+        // issued before them -- all of iterations < i -- has completed.  The asm ties the counter store to the
+        // last consumed operand so the compiler cannot hoist it above that wait.
+        if (i > 0) {
+            asm volatile("" ::"v"(S.duL), "v"(S.dvL) : "memory");
+            if (is0) __hip_atomic_store(my_prog, (unsigned)min(ns, i * R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    // final publication: every store of this wave has left the CU before the counter moves (guide G16/R1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (is0) __hip_atomic_store(my_prog, (unsigned)ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -383,8 +445,8 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
     if (mode == PAPOF_SOR_EXACT) {
         if (!sp.skew) return PAPOF_EINVAL;
         const SkewDims sd = skew_dims(H, W);
-        if ((sd.n + kLanes) * sizeof(double) >= (size_t(1) << 32)) return PAPOF_EINVAL;  // 32-bit element offsets
-        const size_t words = (size_t)sd.nb * n_sor + 4;
+        if ((sd.n + kLanes) * 16 >= (size_t(1) << 32)) return PAPOF_EINVAL;  // 32-bit byte offsets into a paired plane
+        const size_t words = (size_t)sd.nb * n_sor * kProgStride + kProgStride;
         if (words > h->sync_cap) {
             PAPOF_HIP(hipStreamSynchronize(h->stream));
             if (h->sync_words) PAPOF_HIP(hipFree(h->sync_words));
@@ -395,13 +457,13 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             h->sync_cap = cap;
             PAPOF_HIP(hipMemsetAsync(h->sync_words, 0, cap * sizeof(unsigned), h->stream));
         }
-        // word 0..3: abort block (kept across solves; checked by sor_check), counters start at word 4
-        unsigned* prog = h->sync_words + 4;
-        const size_t nbytes = (((size_t)sd.nb * n_sor * sizeof(unsigned)) + 15) & ~size_t(15);
+        // first line: abort word (kept across solves; checked by sor_check); counters start at the second line
+        unsigned* prog = h->sync_words + kProgStride;
+        const size_t nbytes = (size_t)sd.nb * n_sor * kProgStride * sizeof(unsigned);
         PAPOF_HIP(hipMemsetAsync(prog, 0, nbytes, h->stream));
         ExactArgs A;
         A.phi = sp.phi;
-        A.xy = sp.xy;
+        A.xy = sp.xy;  // paired planes: only phi / a1 / b1 / du are used as the four plane bases
         A.a1 = sp.a1;
         A.a2 = sp.a2;
         A.b1 = sp.b1;
@@ -416,13 +478,21 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.ns = sd.ns;
         A.nsp = sd.nsp;
         A.n_sor = n_sor;
-        A.chunk = std::max(2 * U, h->sor_chunk / (2 * U) * (2 * U));
+        A.chunk = 0;
         A.nalpha = nalpha;
         A.om1 = om1;
-        if (h->use_dpp)
-            hipLaunchKernelGGL(k_sor_exact<true>, dim3(sd.nb * n_sor), dim3(kLanes), 0, h->stream, A);
+        const dim3 grid(sd.nb * n_sor), block(kLanes);
+        const int R = h->sor_depth;
+        if (!h->use_dpp)
+            hipLaunchKernelGGL((k_sor_exact<8, false>), grid, block, 0, h->stream, A);
+        else if (R <= 6)
+            hipLaunchKernelGGL((k_sor_exact<6, true>), grid, block, 0, h->stream, A);
+        else if (R <= 8)
+            hipLaunchKernelGGL((k_sor_exact<8, true>), grid, block, 0, h->stream, A);
+        else if (R <= 10)
+            hipLaunchKernelGGL((k_sor_exact<10, true>), grid, block, 0, h->stream, A);
         else
-            hipLaunchKernelGGL(k_sor_exact<false>, dim3(sd.nb * n_sor), dim3(kLanes), 0, h->stream, A);
+            hipLaunchKernelGGL((k_sor_exact<12, true>), grid, block, 0, h->stream, A);
         PAPOF_HIP(hipGetLastError());
         return PAPOF_OK;
     }
@@ -468,10 +538,41 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
 // zeros, so one memset per (level, plane) suffices.
 int sor_reset_planes(papof_handle* h, const SorPlanes& sp, int H, int W) {
     if (!sp.skew) return PAPOF_OK;
-    const size_t bytes = (skew_dims(H, W).n + kLanes) * sizeof(double);
-    double* planes[8] = {sp.phi, sp.xy, sp.a1, sp.a2, sp.b1, sp.b2, sp.du, sp.dv};
-    for (double* p : planes) PAPOF_HIP(hipMemsetAsync(p, 0, bytes, h->stream));
+    const size_t bytes = (skew_dims(H, W).n + kLanes) * 16;
+    double* pairs[4] = {sp.phi, sp.a1, sp.b1, sp.du};
+    for (double* p : pairs) PAPOF_HIP(hipMemsetAsync(p, 0, bytes, h->stream));
     return PAPOF_OK;
+}
+
+int sor_alloc_planes(Arena& A, int H, int W, int mode, SorPlanes& sp) {
+    sp.skew = mode == PAPOF_SOR_EXACT;
+    sp.du2 = sp.dv2 = nullptr;
+    if (sp.skew) {
+        const size_t n = 2 * (skew_dims(H, W).n + kLanes);  // doubles per paired plane
+        sp.phi = A.f64(n);
+        sp.xy = sp.phi ? sp.phi + 1 : nullptr;
+        sp.a1 = A.f64(n);
+        sp.a2 = sp.a1 ? sp.a1 + 1 : nullptr;
+        sp.b1 = A.f64(n);
+        sp.b2 = sp.b1 ? sp.b1 + 1 : nullptr;
+        sp.du = A.f64(n);
+        sp.dv = sp.du ? sp.du + 1 : nullptr;
+    } else {
+        const size_t n = (size_t)H * W;
+        sp.phi = A.f64(n);
+        sp.xy = A.f64(n);
+        sp.a1 = A.f64(n);
+        sp.a2 = A.f64(n);
+        sp.b1 = A.f64(n);
+        sp.b2 = A.f64(n);
+        sp.du = A.f64(n);
+        sp.dv = A.f64(n);
+        if (mode == PAPOF_SOR_JACOBI) {
+            sp.du2 = A.f64(n);
+            sp.dv2 = A.f64(n);
+        }
+    }
+    return A.overflow ? PAPOF_ENOMEM : PAPOF_OK;
 }
 
 int sor_probe_dpp(papof_handle* h) {
