@@ -4,8 +4,8 @@
 // src/Image.h:469):
 //   * images / features are PLANAR: plane k of an H x W x C image is a dense row-major H*W array at
 //     base + k*H*W (the reference's interleaved HWC layout is converted once on entry and once on exit);
-//   * the eight SOR operands of the exact-order solver use the per-band SKEWED layout documented in
-//     sor.hip (64-row bands, element (r, j) of band b at ((b*NS + j + r)*64 + r), NS = W + 63).
+//   * the eight SOR operands of the exact-order solver use the per-band SKEWED, PAIRED layout documented in
+//     sor.hip (62-row bands + 2 ghost lanes, cell (lane l, column j) of band b at ((b*NSP + j + l)*64 + l)).
 //
 // All device code is compiled with -ffp-contract=off: the reference is built without FMA
 // (Code/Serial/setup.py:24-25, plain x86-64 gcc), and matching its rounding step for step is what
@@ -72,8 +72,10 @@ struct Arena {
 
 constexpr int kSorMaxDepth = 32;  // largest software-pipeline depth (steps) of the exact-order SOR kernel
 
+constexpr int kBandRows = kLanes - 2;  // real rows per band: lanes 1..62; lanes 0 / 63 mirror the rows above / below
+
 struct SkewDims {
-    int nb;     // bands of 64 rows
+    int nb;     // bands of kBandRows rows
     int ns;     // steps per task that touch real cells = W + 63
     int nsp;    // band stride in skew positions: ns rounded up plus two pipeline depths of spare positions, so the
                 // kernel may run / prefetch whole iterations past ns without leaving its own band
@@ -81,7 +83,7 @@ struct SkewDims {
 };
 inline SkewDims skew_dims(int h, int w) {
     SkewDims d;
-    d.nb = (h + kLanes - 1) / kLanes;
+    d.nb = (h + kBandRows - 1) / kBandRows;
     d.ns = w + kLanes - 1;
     d.nsp = (d.ns + kSorMaxDepth - 1) / kSorMaxDepth * kSorMaxDepth + 2 * kSorMaxDepth;
     d.n = (size_t)d.nb * d.nsp * kLanes;

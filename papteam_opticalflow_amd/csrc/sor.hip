@@ -86,44 +86,38 @@ __device__ __forceinline__ bool wait_ge(unsigned* p, unsigned need, unsigned* ab
     return true;
 }
 
-// Cross-lane move of one fp64 value by one lane, with the wave-edge lane taking `edge` instead:
-//   from_above(edge, x): lane r <- x of lane r-1 ; lane 0  <- its own `edge`
-//   from_below(edge, x): lane r <- x of lane r+1 ; lane 63 <- its own `edge`
-// DPP wave_shr:1 / wave_shl:1 (GFX9 full-wavefront shifts, dpp_ctrl 0x138 / 0x130; a lane without a source keeps
-// the `old` operand when bound_ctrl = 0) when the start-up probe verified that behaviour on this device,
-// else ds_bpermute + select.
+// Cross-lane move of one fp64 value by one lane (the wave-edge lane receives an unspecified value that the
+// ghost-lane scheme never uses).  DPP wave_shr:1 / wave_shl:1 (GFX9 full-wavefront shifts, dpp_ctrl 0x138 / 0x130)
+// when the start-up probe verified their direction on this device, else ds_bpermute.
 template <bool DPP>
-__device__ __forceinline__ double from_above(double edge, double x, bool is0) {
+__device__ __forceinline__ double from_above(double x) {  // lane l <- lane l-1
     if (DPP) {
-        int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(x), 0x138, 0xf, 0xf, false);
-        int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(x), 0x138, 0xf, 0xf, false);
+        int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, true);
+        int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, true);
         return __hiloint2double(hi, lo);
     }
-    const double y = __shfl_up(x, 1);
-    return is0 ? edge : y;
+    return __shfl_up(x, 1);
 }
 template <bool DPP>
-__device__ __forceinline__ double from_below(double edge, double x, bool is63) {
+__device__ __forceinline__ double from_below(double x) {  // lane l <- lane l+1
     if (DPP) {
-        int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(x), 0x130, 0xf, 0xf, false);
-        int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(x), 0x130, 0xf, 0xf, false);
+        int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xf, 0xf, true);
+        int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xf, 0xf, true);
         return __hiloint2double(hi, lo);
     }
-    const double y = __shfl_down(x, 1);
-    return is63 ? edge : y;
+    return __shfl_down(x, 1);
 }
 
 __global__ void k_xlane_probe(int* out) {  // out[0..63] = from_above, out[64..127] = from_below (DPP forms)
     const int lane = threadIdx.x;
-    const double v = (double)(lane + 1), edge = (double)(1000 + lane);
-    out[lane] = (int)from_above<true>(edge, v, lane == 0);
-    out[64 + lane] = (int)from_below<true>(edge, v, lane == 63);
+    const double v = (double)(lane + 1);
+    out[lane] = (int)from_above<true>(v);
+    out[64 + lane] = (int)from_below<true>(v);
 }
 
 // ---- 16-byte accesses through buffer descriptors (one SGPR quad per paired plane) -------------------------
-// voffset = lane * 16 (a constant VGPR), soffset = wave-uniform byte offset of the step: all address arithmetic is
-// scalar.  aux = 16 sets `sc1` (agent-coherent: write-through stores, L1-bypassing loads) on the du/dv plane;
-// out-of-range offsets would read 0 / drop the store (num_records = plane size), never fault.
+// aux = 16 sets `sc1` (agent-coherent: write-through stores, L1-bypassing loads) on the du/dv plane.  Offsets
+// beyond num_records read 0 / DROP the store: the kernel uses that to switch lanes off without touching EXEC.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct D2 {
     double x, y;
@@ -140,90 +134,53 @@ __device__ __forceinline__ u32x4 as_u4(double x, double y) {
     return r;
 }
 constexpr int kAuxPlain = 0, kAuxSc1 = 16;
+constexpr unsigned kOob = 0x80000000u;  // byte offset beyond every plane (sor_solve enforces planes < 1 GiB) that
+                                        // cannot wrap while it advances by 1 KiB per step
 
 // Operands of R consecutive steps held in registers: slot t of the running iteration is consumed by step
 // i*R + t and immediately refilled with the operands of step (i+1)*R + t, i.e. every global load is issued
 // R steps before its use, so the latency of the write-through du/dv traffic and of the coefficient streams is
-// hidden behind R steps of arithmetic instead of being paid once per step.  A step costs 4 loads + 1 store of
-// 1 KiB each; R <= 10 keeps the loads in flight within the 6-bit vmcnt range (63) of gfx9.
+// hidden behind R steps of arithmetic.  A step costs 4 loads + 2 stores; R <= 9 keeps the operations in
+// flight within the 6-bit vmcnt range (63) of gfx9.
 template <int R>
 struct Slots {
-    u32x4 pa[R], pb[R], pc[R];  // (phi, xy) (a1, a2) (b1, b2) of this lane's cell (r, s - r)
-    u32x4 pd[R];                // right-old (du, dv) = skew position s + 1, previous sweep
-};
-
-// Halo values of R consecutive steps, one step per lane, rotated by one lane after every step so that the
-// lane that needs them always holds the current step's value:
-//   up block: lane l = row above, column of step base + l        -> lane 0 reads it, block rotates downwards
-//   dn block: lane 63 - l = row below, column of step base + l   -> lane 63 reads it, block rotates upwards
-struct Halo {
-    double up_du, up_dv, up_phi, dn_du, dn_dv;
+    u32x4 pa[R], pb[R], pc[R];  // (phi, xy) (a1, a2) (b1, b2) of this lane's cell at skew position s
+    u32x4 pd[R];                // (du, dv) at skew position s + 1: right-old, the next centre
 };
 
 struct Task {  // wave-uniform task constants (SGPRs)
     __amdgpu_buffer_rsrc_t ra, rb, rc, rd;  // descriptors of the four paired planes
-    unsigned band;      // cell offset of (this band, position 0, lane 0)
-    unsigned up_src;    // cell offset of (band above, position 63, lane 63) for step 0
-    unsigned dn_src;    // cell offset of (band below, position -63, lane 0) for step 0 (wraps; guarded)
-    unsigned zero_src;  // cell offset of a cell of this band that is never real: always reads 0.0
-    bool prev, up_any, dn_any;
-    int W, ns;
+    unsigned band16;                        // byte offset of (this band, position 0, lane 0)
 };
-
-// Halo block for steps [base, base + R): three loads for the whole wave.
-template <int R>
-__device__ __forceinline__ void load_halo(const Task& T, unsigned lane, int base, Halo& h) {
-    const int su = base + (int)lane;                 // step served by this lane of the up block
-    const int sd = base + (kLanes - 1 - (int)lane);  // step served by this lane of the dn block
-    const bool up_ok = T.up_any && (int)lane < R && su < T.W;
-    const bool dn_ok = T.dn_any && (kLanes - 1 - (int)lane) < R && sd >= kLanes - 1 && sd - (kLanes - 1) < T.W;
-    const unsigned qu = (up_ok ? T.up_src + (unsigned)su * kLanes : T.zero_src) * 16u;
-    const unsigned qd = (dn_ok ? T.dn_src + (unsigned)sd * kLanes : T.zero_src) * 16u;
-    const D2 u = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, qu, 0, kAuxSc1));
-    const D2 p = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.ra, qu, 0, kAuxPlain));
-    const D2 d = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, qd, 0, kAuxSc1));
-    h.up_du = u.x;
-    h.up_dv = u.y;
-    h.up_phi = p.x;
-    h.dn_du = d.x;
-    h.dn_dv = d.y;
-}
 
 template <int R, int t>
 __device__ __forceinline__ void load_slot(const Task& T, unsigned lane16, int s, Slots<R>& c) {
-    const unsigned off = (T.band + (unsigned)s * kLanes) * 16u;  // wave-uniform byte offset -> soffset
+    const unsigned off = T.band16 + (unsigned)s * (kLanes * 16u);  // wave-uniform byte offset -> soffset
     c.pa[t] = __builtin_amdgcn_raw_buffer_load_b128(T.ra, lane16, off, kAuxPlain);
     c.pb[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rb, lane16, off, kAuxPlain);
     c.pc[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rc, lane16, off, kAuxPlain);
-    if (T.prev)  // wave-uniform; first sweep: every old value is 0 (src/OpticalFlow.cpp:452-453)
-        c.pd[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rd, lane16, off + kLanes * 16u, kAuxSc1);
-    else
-        c.pd[t] = u32x4{0u, 0u, 0u, 0u};
+    c.pd[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rd, lane16, off + kLanes * 16u, kAuxSc1);
 }
 
 struct State {
     double duL, dvL, phiL, duC, dvC;
+    unsigned st_main, st_halo;  // per-lane absolute byte offsets of this step's two stores (kOob-ish = off)
 };
 
 template <int R, int t, bool DPP>
-__device__ __forceinline__ void step(const ExactArgs& A, const Task& T, unsigned lane16, bool is0, bool is63, int s,
-                                     Slots<R>& c, Halo& h, State& S) {
-    const double nalpha = A.nalpha, om1 = A.om1;
+__device__ __forceinline__ void step(const ExactArgs& A, const Task& T, unsigned lane16, double om1, int s,
+                                     Slots<R>& c, State& S) {
+    const double nalpha = A.nalpha;
     const D2 pa = as_d2(c.pa[t]), pb = as_d2(c.pb[t]), pc = as_d2(c.pc[t]), pd = as_d2(c.pd[t]);
     const double phiC = pa.x, xy = pa.y, duR = pd.x, dvR = pd.y;
-    const double duU = from_above<DPP>(h.up_du, S.duL, is0);
-    const double dvU = from_above<DPP>(h.up_dv, S.dvL, is0);
-    const double phiU = from_above<DPP>(h.up_phi, S.phiL, is0);
-    const double duD = from_below<DPP>(h.dn_du, duR, is63);
-    const double dvD = from_below<DPP>(h.dn_dv, dvR, is63);
-    // rotate the halo blocks to the next step (the lane that fell off the edge keeps a stale, unused value)
-    h.up_du = from_below<DPP>(h.up_du, h.up_du, is63);
-    h.up_dv = from_below<DPP>(h.up_dv, h.up_dv, is63);
-    h.up_phi = from_below<DPP>(h.up_phi, h.up_phi, is63);
-    h.dn_du = from_above<DPP>(h.dn_du, h.dn_du, is0);
-    h.dn_dv = from_above<DPP>(h.dn_dv, h.dn_dv, is0);
-    // Every operand that does not exist (image border, padding, first sweep) is an exact 0.0 here, so the
-    // reference's conditional terms (src/OpticalFlow.cpp:468-495) reduce to adding +-0 in the same order.
+    const double duU = from_above<DPP>(S.duL);
+    const double dvU = from_above<DPP>(S.dvL);
+    const double phiU = from_above<DPP>(S.phiL);
+    const double duD = from_below<DPP>(duR);
+    const double dvD = from_below<DPP>(dvR);
+    // Every operand that does not exist (image border, padding) is an exact 0.0 here, so the reference's
+    // conditional terms (src/OpticalFlow.cpp:468-495) reduce to adding +-0 in the same order.  Ghost lanes
+    // (om1 == 1, a == 0) pass their centre value through: 1*c + 0*(..) == c.
     double s1 = S.phiL * S.duL;
     double s2 = S.phiL * S.dvL;
     s1 += phiC * duR;
@@ -238,24 +195,28 @@ __device__ __forceinline__ void step(const ExactArgs& A, const Task& T, unsigned
     const double duN = om1 * S.duC + pb.x * (pc.x - s1);
     s2 += xy * duN;
     const double dvN = om1 * S.dvC + pb.y * (pc.y - s2);
-    const unsigned off = (T.band + (unsigned)s * kLanes) * 16u;
-    // padding cells compute and store an exact (+-)0
-    __builtin_amdgcn_raw_buffer_store_b128(as_u4(duN, dvN), T.rd, lane16, off, kAuxSc1);
+    const u32x4 out = as_u4(duN, dvN);
+    // own cell (real lanes) and the mirror cell in the neighbouring band's ghost lane (lanes 1 and 62 only);
+    // every other lane carries an out-of-range offset and its store is dropped by the descriptor's range check
+    __builtin_amdgcn_raw_buffer_store_b128(out, T.rd, S.st_main, 0, kAuxSc1);
+    __builtin_amdgcn_raw_buffer_store_b128(out, T.rd, S.st_halo, 0, kAuxSc1);
+    S.st_main += kLanes * 16u;
+    S.st_halo += kLanes * 16u;
     S.duL = duN;
     S.dvL = dvN;
     S.phiL = phiC;
     S.duC = duR;
     S.dvC = dvR;
-    asm volatile("" ::: "memory");  // keep this step's store ahead of its refill loads in the instruction stream
+    asm volatile("" ::: "memory");  // keep this step's stores ahead of its refill loads in the instruction stream
     load_slot<R, t>(T, lane16, s + R, c);  // refill this slot for the step R ahead
 }
 
 template <int R, int t, bool DPP>
 struct Unroll {
-    static __device__ __forceinline__ void run(const ExactArgs& A, const Task& T, unsigned lane16, bool is0,
-                                               bool is63, int s0, Slots<R>& c, Halo& h, State& S) {
-        Unroll<R, t - 1, DPP>::run(A, T, lane16, is0, is63, s0, c, h, S);
-        step<R, t, DPP>(A, T, lane16, is0, is63, s0 + t, c, h, S);
+    static __device__ __forceinline__ void run(const ExactArgs& A, const Task& T, unsigned lane16, double om1, int s0,
+                                               Slots<R>& c, State& S) {
+        Unroll<R, t - 1, DPP>::run(A, T, lane16, om1, s0, c, S);
+        step<R, t, DPP>(A, T, lane16, om1, s0 + t, c, S);
     }
     static __device__ __forceinline__ void fill(const Task& T, unsigned lane16, Slots<R>& c) {
         Unroll<R, t - 1, DPP>::fill(T, lane16, c);
@@ -264,8 +225,8 @@ struct Unroll {
 };
 template <int R, bool DPP>
 struct Unroll<R, -1, DPP> {
-    static __device__ __forceinline__ void run(const ExactArgs&, const Task&, unsigned, bool, bool, int, Slots<R>&,
-                                               Halo&, State&) {}
+    static __device__ __forceinline__ void run(const ExactArgs&, const Task&, unsigned, double, int, Slots<R>&,
+                                               State&) {}
     static __device__ __forceinline__ void fill(const Task&, unsigned, Slots<R>&) {}
 };
 
@@ -313,24 +274,16 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     const int k = task / A.nb, b = task - k * A.nb;
     const int ns = A.ns, nsp = A.nsp;
     const bool has_up = b > 0, has_dn = (b + 1 < A.nb), prev = k > 0;
-    const bool is0 = lane == 0, is63 = lane == kLanes - 1;
+    const bool ghost = lane == 0 || lane == kLanes - 1;
     Task T;
     const unsigned plane_bytes = (unsigned)(((size_t)A.nb * nsp + 1) * kLanes * 16u);
     T.ra = __builtin_amdgcn_make_buffer_rsrc((void*)A.phi, 0, plane_bytes, 0x00020000);
     T.rb = __builtin_amdgcn_make_buffer_rsrc((void*)A.a1, 0, plane_bytes, 0x00020000);
     T.rc = __builtin_amdgcn_make_buffer_rsrc((void*)A.b1, 0, plane_bytes, 0x00020000);
     T.rd = __builtin_amdgcn_make_buffer_rsrc((void*)A.du, 0, plane_bytes, 0x00020000);
-    T.band = (unsigned)b * (unsigned)nsp * kLanes;
-    T.prev = prev;
-    T.up_any = has_up;
-    T.dn_any = prev && has_dn;
-    T.W = A.W;
-    T.ns = ns;
-    // (band above, position s + 63, lane 63) and (band below, position s - 63, lane 0), relative to step 0;
-    // the unsigned wrap of the unused / early ones is harmless: they are only dereferenced when *_ok holds.
-    T.up_src = ((unsigned)(b - 1) * (unsigned)nsp + (kLanes - 1)) * kLanes + (kLanes - 1);
-    T.dn_src = ((unsigned)(b + 1) * (unsigned)nsp - (kLanes - 1)) * kLanes;
-    T.zero_src = T.band + (unsigned)(nsp - 1) * kLanes;  // last spare position of this band: never a real cell
+    T.band16 = (unsigned)b * (unsigned)nsp * (kLanes * 16u);
+    const double om1 = ghost ? 1.0 : A.om1;  // ghost lanes pass their (mirrored) centre value through unchanged
+
     // one 128-byte line per counter: hundreds of waves publish and poll concurrently, and counters sharing a
     // line would serialise at the memory side
     unsigned* const my_prog = A.prog + ((size_t)k * A.nb + b) * kProgStride;
@@ -339,28 +292,35 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     unsigned* const p_dn = A.prog + ((size_t)(k - 1) * A.nb + (b + 1)) * kProgStride;
 
     const int n_iter = (ns + R - 1) / R;  // steps beyond ns only touch padding (nsp >= n_iter*R + R + 1)
-    State S{0.0, 0.0, 0.0, 0.0, 0.0};
+    State S;
+    S.duL = S.dvL = S.phiL = 0.0;
+    // Store targets at step 0 (all advance by one skew position = 1 KiB per step):
+    //   real lane l        -> own cell (band b, position s, lane l)
+    //   lane 1  (first row)-> also ghost lane 63 of band b-1: that band sees column j at position j + 63, and
+    //                         lane 1 is at column s - 1, i.e. position s + 62 there
+    //   lane 62 (last row) -> also ghost lane 0 of band b+1: column j = s - 62 sits at position s - 62 there
+    //                         (negative positions wrap to huge offsets and are dropped like every kOob store)
+    S.st_main = ghost ? kOob : T.band16 + lane16;
+    S.st_halo = kOob;
+    if (lane == 1 && has_up) S.st_halo = T.band16 - (unsigned)nsp * (kLanes * 16u) + 62u * (kLanes * 16u) + 63u * 16u;
+    if (lane == kLanes - 2 && has_dn) S.st_halo = T.band16 + (unsigned)nsp * (kLanes * 16u) - 62u * (kLanes * 16u);
     Slots<R> c;
-    Halo h, hn;
 
-    // Before iteration i every load it issues (slots and halo block of iteration i + 1) must be covered:
-    // producers' progress for steps < (i + 2) * R.  The polls themselves are prefetched one iteration ahead.
+    // Before iteration i every load it issues (slots of iteration i + 1) must be covered: producers' progress for
+    // steps < (i + 2) * R.  The polls themselves are prefetched one iteration ahead.
     Polls pl = poll(p_own, p_up, p_dn, prev, has_up, has_dn);
     if (!wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, 2 * R)) return;
-    if (prev) {  // centre of the first cell (skew position 0: a real cell for lane 0, padding = 0 for the others)
-        const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, lane16, T.band * 16u, kAuxSc1));
+    {  // centre of the first cells (skew position 0)
+        const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, lane16, T.band16, kAuxSc1));
         S.duC = c0.x;
         S.dvC = c0.y;
     }
-    load_halo<R>(T, lane, 0, h);
     Unroll<R, R - 1, DPP>::fill(T, lane16, c);
 
     for (int i = 0; i < n_iter; ++i) {
         if (i > 0 && !wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, (i + 2) * R)) return;
-        load_halo<R>(T, lane, (i + 1) * R, hn);                             // halo block of iteration i + 1
-        const Polls pn = poll(p_own, p_up, p_dn, prev, has_up, has_dn);     // poll for iteration i + 1
-        Unroll<R, R - 1, DPP>::run(A, T, lane16, is0, is63, i * R, c, h, S);
-        h = hn;
+        const Polls pn = poll(p_own, p_up, p_dn, prev, has_up, has_dn);  // poll for iteration i + 1
+        Unroll<R, R - 1, DPP>::run(A, T, lane16, om1, i * R, c, S);
         pl = pn;
         // Lagged publication without draining the memory pipeline: vmcnt retires in issue order, so once the
         // slot loads issued during iteration i-1 have been consumed (all of them were, just above), every store
@@ -368,12 +328,13 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
         // last consumed operand so the compiler cannot hoist it above that wait.
         if (i > 0) {
             asm volatile("" ::"v"(S.duL), "v"(S.dvL) : "memory");
-            if (is0) __hip_atomic_store(my_prog, (unsigned)min(ns, i * R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0)
+                __hip_atomic_store(my_prog, (unsigned)min(ns, i * R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // final publication: every store of this wave has left the CU before the counter moves (guide G16/R1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (is0) __hip_atomic_store(my_prog, (unsigned)ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(my_prog, (unsigned)ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -445,7 +406,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
     if (mode == PAPOF_SOR_EXACT) {
         if (!sp.skew) return PAPOF_EINVAL;
         const SkewDims sd = skew_dims(H, W);
-        if ((sd.n + kLanes) * 16 >= (size_t(1) << 32)) return PAPOF_EINVAL;  // 32-bit byte offsets into a paired plane
+        if ((sd.n + kLanes) * 16 >= (size_t(1) << 30)) return PAPOF_EINVAL;  // 32-bit byte offsets, see kOob
         const size_t words = (size_t)sd.nb * n_sor * kProgStride + kProgStride;
         if (words > h->sync_cap) {
             PAPOF_HIP(hipStreamSynchronize(h->stream));
@@ -481,18 +442,20 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.chunk = 0;
         A.nalpha = nalpha;
         A.om1 = om1;
+        // du = dv = 0 before the first sweep (src/OpticalFlow.cpp:452-453); also clears the ghost-lane mirrors
+        PAPOF_HIP(hipMemsetAsync(sp.du, 0, (sd.n + kLanes) * 16, h->stream));
         const dim3 grid(sd.nb * n_sor), block(kLanes);
         const int R = h->sor_depth;
         if (!h->use_dpp)
             hipLaunchKernelGGL((k_sor_exact<8, false>), grid, block, 0, h->stream, A);
+        else if (R <= 4)
+            hipLaunchKernelGGL((k_sor_exact<4, true>), grid, block, 0, h->stream, A);
         else if (R <= 6)
             hipLaunchKernelGGL((k_sor_exact<6, true>), grid, block, 0, h->stream, A);
         else if (R <= 8)
             hipLaunchKernelGGL((k_sor_exact<8, true>), grid, block, 0, h->stream, A);
-        else if (R <= 10)
-            hipLaunchKernelGGL((k_sor_exact<10, true>), grid, block, 0, h->stream, A);
         else
-            hipLaunchKernelGGL((k_sor_exact<12, true>), grid, block, 0, h->stream, A);
+            hipLaunchKernelGGL((k_sor_exact<9, true>), grid, block, 0, h->stream, A);
         PAPOF_HIP(hipGetLastError());
         return PAPOF_OK;
     }
@@ -592,7 +555,6 @@ int sor_probe_dpp(papof_handle* h) {
     bool ok = true;
     for (int l = 1; l < 64; l++) ok = ok && host[l] == l;             // lane l sees lane l-1 (value l-1+1)
     for (int l = 0; l < 63; l++) ok = ok && host[64 + l] == l + 2;    // lane l sees lane l+1 (value l+1+1)
-    ok = ok && host[0] == 1000 && host[127] == 1063;                  // edge lanes keep their own `edge` operand
     h->use_dpp = ok;
     if (const char* s = std::getenv("PAPOF_SOR_XLANE")) {
         if (std::strcmp(s, "shfl") == 0) h->use_dpp = false;
