@@ -221,15 +221,6 @@ __device__ __forceinline__ size_t sor_index(int i, int j, int W, int nsp) {
     return (size_t)i * W + j;
 }
 
-// Exact-order solver layout: the last real row of a band is mirrored into ghost lane 0 of the band below, which
-// only needs its weight phi (the upper-neighbour weight of the band's first real row); all other operands of a
-// ghost cell stay 0.  Ghost lane 63 (row below) needs no coefficient at all.
-__device__ __forceinline__ void ghost_phi(double* __restrict__ o_phi, double v, int i, int j, int H, int nsp) {
-    const int b = i / kBandRows;
-    if (i - b * kBandRows == kBandRows - 1 && i + 1 < H)
-        o_phi[2 * (((size_t)(b + 1) * nsp + j) * kLanes)] = v;  // band b+1, lane 0, position j + 0
-}
-
 // OpticalFlow::Laplacian at one cell, src/OpticalFlow.cpp:641-690: column W-1 receives no horizontal
 // term and row H-1 no vertical term (the loops stop at W-2 / H-2).
 __device__ __forceinline__ double laplacian_at(const double* __restrict__ in, const double* __restrict__ wt, int i,
@@ -332,7 +323,6 @@ __global__ void k_assemble(const double* __restrict__ blend, const double* __res
     sor_diagonals(phi, i, j, H, W, sx2, sy2, alpha, omega, a1, a2);
     const size_t q = sor_index<SKEW>(i, j, W, ns);
     o_phi[q] = phi[o];
-    if (SKEW) ghost_phi(o_phi, phi[o], i, j, H, ns);
     o_xy[q] = sxy;
     o_a1[q] = a1;
     o_a2[q] = a2;
@@ -357,7 +347,6 @@ __global__ void k_sor_prep(const double* __restrict__ phi, const double* __restr
     sor_diagonals(phi, i, j, H, W, imdx2[o], imdy2[o], alpha, omega, a1, a2);
     const size_t q = sor_index<SKEW>(i, j, W, ns);
     o_phi[q] = phi[o];
-    if (SKEW) ghost_phi(o_phi, phi[o], i, j, H, ns);
     o_xy[q] = imdxy[o];
     o_a1[q] = a1;
     o_a2[q] = a2;

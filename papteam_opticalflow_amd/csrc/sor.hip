@@ -41,6 +41,7 @@
 // PAPOF_SOR_REDBLACK / PAPOF_SOR_JACOBI -- one launch per half-sweep / sweep on row-major planes;
 //   throughput and correctness-gate modes whose results differ from the reference's order.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -115,6 +116,44 @@ __global__ void k_xlane_probe(int* out) {  // out[0..63] = from_above, out[64..1
     out[64 + lane] = (int)from_below<true>(v);
 }
 
+// Diagnostic (PAPOF_PROBE=1 at handle creation): cost of the per-step arithmetic alone, one wave, no memory.
+// out[0] = s_memtime ticks, out[1] = s_memrealtime ticks (100 MHz) for `n` steps.
+__global__ __launch_bounds__(64) void k_alu_probe(unsigned long long* out, double* sink, int n, double seed) {
+    double duL = seed, dvL = seed * 0.5, phiL = 0.7, duC = 0.1, dvC = 0.2;
+    const double phiC = 0.9, xy = 0.01, a1 = 0.3, a2 = 0.4, b1 = 0.001, b2 = 0.002, nalpha = -0.012, om1 = -0.8;
+    double duR = 0.05 * seed, dvR = 0.06 * seed;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < n; i++) {
+        const double duU = from_above<true>(duL), dvU = from_above<true>(dvL), phiU = from_above<true>(phiL);
+        const double duD = from_below<true>(duR), dvD = from_below<true>(dvR);
+        double s1 = phiL * duL, s2 = phiL * dvL;
+        s1 += phiC * duR;
+        s2 += phiC * dvR;
+        s1 += phiU * duU;
+        s2 += phiU * dvU;
+        s1 += phiC * duD;
+        s2 += phiC * dvD;
+        s1 *= nalpha;
+        s2 *= nalpha;
+        s1 += xy * dvC;
+        const double duN = om1 * duC + a1 * (b1 - s1);
+        s2 += xy * duN;
+        const double dvN = om1 * dvC + a2 * (b2 - s2);
+        duL = duN;
+        dvL = dvN;
+        duC = duR;
+        dvC = dvR;
+        duR = duR * 0.999;
+        dvR = dvR * 0.999;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[0] = t1 - t0;
+        out[1] = r1 - r0;
+    }
+    sink[threadIdx.x] = duL + dvL;
+}
+
 // ---- 16-byte accesses through buffer descriptors (one SGPR quad per paired plane) -------------------------
 // aux = 16 sets `sc1` (agent-coherent: write-through stores, L1-bypassing loads) on the du/dv plane.  Offsets
 // beyond num_records read 0 / DROP the store: the kernel uses that to switch lanes off without touching EXEC.
@@ -150,25 +189,36 @@ struct Slots {
 
 struct Task {  // wave-uniform task constants (SGPRs)
     __amdgpu_buffer_rsrc_t ra, rb, rc, rd;  // descriptors of the four paired planes
-    unsigned band16;                        // byte offset of (this band, position 0, lane 0)
+};
+
+// Per-lane ABSOLUTE byte offsets (constant VGPRs); the step index enters only through the uniform soffset
+// s * 1 KiB.  Real lanes (1..62) address their own cell of this band.  Ghost lanes read straight from the
+// neighbouring band's cells instead of keeping mirrored copies:
+//   lane 0  = the row above  = (band b-1, lane 62): column j sits at that band's skew position j + 62
+//   lane 63 = the row below  = (band b+1, lane 1) : column j sits at that band's skew position j + 1
+// and never store.  kOob switches an access off (reads 0.0, drops the store) without touching EXEC.
+struct LaneOffs {
+    unsigned pa;   // (phi, xy) at this lane's column of step s          [ghost above: phi of that row; below: off]
+    unsigned pbc;  // (a1, a2) and (b1, b2)                              [ghosts: off -> 0 -> pass-through]
+    unsigned pd;   // (du, dv) at the column of step s + 1 (right-old / next centre)
+    unsigned st;   // (du, dv) store at this lane's column of step s     [ghosts: off]
 };
 
 template <int R, int t>
-__device__ __forceinline__ void load_slot(const Task& T, unsigned lane16, int s, Slots<R>& c) {
-    const unsigned off = T.band16 + (unsigned)s * (kLanes * 16u);  // wave-uniform byte offset -> soffset
-    c.pa[t] = __builtin_amdgcn_raw_buffer_load_b128(T.ra, lane16, off, kAuxPlain);
-    c.pb[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rb, lane16, off, kAuxPlain);
-    c.pc[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rc, lane16, off, kAuxPlain);
-    c.pd[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rd, lane16, off + kLanes * 16u, kAuxSc1);
+__device__ __forceinline__ void load_slot(const Task& T, const LaneOffs& L, int s, Slots<R>& c) {
+    const unsigned off = (unsigned)s * (kLanes * 16u);  // wave-uniform byte offset -> soffset
+    c.pa[t] = __builtin_amdgcn_raw_buffer_load_b128(T.ra, L.pa, off, kAuxPlain);
+    c.pb[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rb, L.pbc, off, kAuxPlain);
+    c.pc[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rc, L.pbc, off, kAuxPlain);
+    c.pd[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rd, L.pd, off, kAuxSc1);
 }
 
 struct State {
     double duL, dvL, phiL, duC, dvC;
-    unsigned st_main, st_halo;  // per-lane absolute byte offsets of this step's two stores (kOob-ish = off)
 };
 
 template <int R, int t, bool DPP>
-__device__ __forceinline__ void step(const ExactArgs& A, const Task& T, unsigned lane16, double om1, int s,
+__device__ __forceinline__ void step(const ExactArgs& A, const Task& T, const LaneOffs& L, double om1, int s,
                                      Slots<R>& c, State& S) {
     const double nalpha = A.nalpha;
     const D2 pa = as_d2(c.pa[t]), pb = as_d2(c.pb[t]), pc = as_d2(c.pc[t]), pd = as_d2(c.pd[t]);
@@ -180,7 +230,7 @@ __device__ __forceinline__ void step(const ExactArgs& A, const Task& T, unsigned
     const double dvD = from_below<DPP>(dvR);
     // Every operand that does not exist (image border, padding) is an exact 0.0 here, so the reference's
     // conditional terms (src/OpticalFlow.cpp:468-495) reduce to adding +-0 in the same order.  Ghost lanes
-    // (om1 == 1, a == 0) pass their centre value through: 1*c + 0*(..) == c.
+    // (om1 == 1, a1 == a2 == 0) pass their centre value through: 1*c + 0*(..) == c.
     double s1 = S.phiL * S.duL;
     double s2 = S.phiL * S.dvL;
     s1 += phiC * duR;
@@ -195,39 +245,33 @@ __device__ __forceinline__ void step(const ExactArgs& A, const Task& T, unsigned
     const double duN = om1 * S.duC + pb.x * (pc.x - s1);
     s2 += xy * duN;
     const double dvN = om1 * S.dvC + pb.y * (pc.y - s2);
-    const u32x4 out = as_u4(duN, dvN);
-    // own cell (real lanes) and the mirror cell in the neighbouring band's ghost lane (lanes 1 and 62 only);
-    // every other lane carries an out-of-range offset and its store is dropped by the descriptor's range check
-    __builtin_amdgcn_raw_buffer_store_b128(out, T.rd, S.st_main, 0, kAuxSc1);
-    __builtin_amdgcn_raw_buffer_store_b128(out, T.rd, S.st_halo, 0, kAuxSc1);
-    S.st_main += kLanes * 16u;
-    S.st_halo += kLanes * 16u;
+    __builtin_amdgcn_raw_buffer_store_b128(as_u4(duN, dvN), T.rd, L.st, (unsigned)s * (kLanes * 16u), kAuxSc1);
     S.duL = duN;
     S.dvL = dvN;
     S.phiL = phiC;
     S.duC = duR;
     S.dvC = dvR;
-    asm volatile("" ::: "memory");  // keep this step's stores ahead of its refill loads in the instruction stream
-    load_slot<R, t>(T, lane16, s + R, c);  // refill this slot for the step R ahead
+    asm volatile("" ::: "memory");  // keep this step's store ahead of its refill loads in the instruction stream
+    load_slot<R, t>(T, L, s + R, c);  // refill this slot for the step R ahead
 }
 
 template <int R, int t, bool DPP>
 struct Unroll {
-    static __device__ __forceinline__ void run(const ExactArgs& A, const Task& T, unsigned lane16, double om1, int s0,
-                                               Slots<R>& c, State& S) {
-        Unroll<R, t - 1, DPP>::run(A, T, lane16, om1, s0, c, S);
-        step<R, t, DPP>(A, T, lane16, om1, s0 + t, c, S);
+    static __device__ __forceinline__ void run(const ExactArgs& A, const Task& T, const LaneOffs& L, double om1,
+                                               int s0, Slots<R>& c, State& S) {
+        Unroll<R, t - 1, DPP>::run(A, T, L, om1, s0, c, S);
+        step<R, t, DPP>(A, T, L, om1, s0 + t, c, S);
     }
-    static __device__ __forceinline__ void fill(const Task& T, unsigned lane16, Slots<R>& c) {
-        Unroll<R, t - 1, DPP>::fill(T, lane16, c);
-        load_slot<R, t>(T, lane16, t, c);
+    static __device__ __forceinline__ void fill(const Task& T, const LaneOffs& L, Slots<R>& c) {
+        Unroll<R, t - 1, DPP>::fill(T, L, c);
+        load_slot<R, t>(T, L, t, c);
     }
 };
 template <int R, bool DPP>
 struct Unroll<R, -1, DPP> {
-    static __device__ __forceinline__ void run(const ExactArgs&, const Task&, unsigned, double, int, Slots<R>&,
+    static __device__ __forceinline__ void run(const ExactArgs&, const Task&, const LaneOffs&, double, int, Slots<R>&,
                                                State&) {}
-    static __device__ __forceinline__ void fill(const Task&, unsigned, Slots<R>&) {}
+    static __device__ __forceinline__ void fill(const Task&, const LaneOffs&, Slots<R>&) {}
 };
 
 // Progress of the three producers of a task, polled together (a missing producer reads as "finished").
@@ -245,7 +289,7 @@ __device__ __forceinline__ Polls poll(unsigned* p_own, unsigned* p_up, unsigned*
 // May every load that touches steps < s_end be issued?  (see the dependency table in the file header)
 __device__ __forceinline__ bool covered(const Polls& p, int ns, int s_end) {
     return p.own >= (unsigned)min(ns, s_end + 1) && p.up >= (unsigned)min(ns, s_end + 63) &&
-           p.dn >= (unsigned)min(ns, max(0, s_end - 63));
+           p.dn >= (unsigned)min(ns, max(0, s_end - 60));
 }
 
 // Bounded wave-uniform wait until the producers cover steps < s_end.  false = abort / timeout.
@@ -281,8 +325,26 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     T.rb = __builtin_amdgcn_make_buffer_rsrc((void*)A.a1, 0, plane_bytes, 0x00020000);
     T.rc = __builtin_amdgcn_make_buffer_rsrc((void*)A.b1, 0, plane_bytes, 0x00020000);
     T.rd = __builtin_amdgcn_make_buffer_rsrc((void*)A.du, 0, plane_bytes, 0x00020000);
-    T.band16 = (unsigned)b * (unsigned)nsp * (kLanes * 16u);
-    const double om1 = ghost ? 1.0 : A.om1;  // ghost lanes pass their (mirrored) centre value through unchanged
+    constexpr unsigned kPos = kLanes * 16u;  // bytes per skew position (one 1-KiB wave access)
+    const unsigned band16 = (unsigned)b * (unsigned)nsp * kPos;
+    const unsigned up16 = band16 - (unsigned)nsp * kPos, dn16 = band16 + (unsigned)nsp * kPos;
+    LaneOffs L;
+    L.pa = band16 + lane16;
+    L.pbc = band16 + lane16;
+    L.pd = band16 + kPos + lane16;
+    L.st = band16 + lane16;
+    if (lane == 0) {  // the row above: band b-1, lane 62, column j at position j + 62
+        L.pa = has_up ? up16 + 62u * kPos + 62u * 16u : kOob;
+        L.pd = has_up ? up16 + 63u * kPos + 62u * 16u : kOob;
+        L.pbc = L.st = kOob;
+    }
+    if (lane == kLanes - 1) {  // the row below: band b+1, lane 1, column j at position j + 1; this lane is at
+                               // column s - 63, so its next centre (column s - 62) sits at position s - 61 there
+        L.pa = kOob;
+        L.pd = has_dn ? dn16 - 61u * kPos + 16u : kOob;
+        L.pbc = L.st = kOob;
+    }
+    const double om1 = ghost ? 1.0 : A.om1;  // ghost lanes pass their centre value through unchanged
 
     // one 128-byte line per counter: hundreds of waves publish and poll concurrently, and counters sharing a
     // line would serialise at the memory side
@@ -294,33 +356,24 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     const int n_iter = (ns + R - 1) / R;  // steps beyond ns only touch padding (nsp >= n_iter*R + R + 1)
     State S;
     S.duL = S.dvL = S.phiL = 0.0;
-    // Store targets at step 0 (all advance by one skew position = 1 KiB per step):
-    //   real lane l        -> own cell (band b, position s, lane l)
-    //   lane 1  (first row)-> also ghost lane 63 of band b-1: that band sees column j at position j + 63, and
-    //                         lane 1 is at column s - 1, i.e. position s + 62 there
-    //   lane 62 (last row) -> also ghost lane 0 of band b+1: column j = s - 62 sits at position s - 62 there
-    //                         (negative positions wrap to huge offsets and are dropped like every kOob store)
-    S.st_main = ghost ? kOob : T.band16 + lane16;
-    S.st_halo = kOob;
-    if (lane == 1 && has_up) S.st_halo = T.band16 - (unsigned)nsp * (kLanes * 16u) + 62u * (kLanes * 16u) + 63u * 16u;
-    if (lane == kLanes - 2 && has_dn) S.st_halo = T.band16 + (unsigned)nsp * (kLanes * 16u) - 62u * (kLanes * 16u);
     Slots<R> c;
 
     // Before iteration i every load it issues (slots of iteration i + 1) must be covered: producers' progress for
     // steps < (i + 2) * R.  The polls themselves are prefetched one iteration ahead.
     Polls pl = poll(p_own, p_up, p_dn, prev, has_up, has_dn);
     if (!wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, 2 * R)) return;
-    {  // centre of the first cells (skew position 0)
-        const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, lane16, T.band16, kAuxSc1));
+    {  // centre of the first cells: the (du, dv) one skew position before the step-0 right-old
+        const unsigned first = (L.pd == kOob) ? kOob : L.pd - kPos;
+        const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, first, 0, kAuxSc1));
         S.duC = c0.x;
         S.dvC = c0.y;
     }
-    Unroll<R, R - 1, DPP>::fill(T, lane16, c);
+    Unroll<R, R - 1, DPP>::fill(T, L, c);
 
     for (int i = 0; i < n_iter; ++i) {
         if (i > 0 && !wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, (i + 2) * R)) return;
         const Polls pn = poll(p_own, p_up, p_dn, prev, has_up, has_dn);  // poll for iteration i + 1
-        Unroll<R, R - 1, DPP>::run(A, T, lane16, om1, i * R, c, S);
+        Unroll<R, R - 1, DPP>::run(A, T, L, om1, i * R, c, S);
         pl = pn;
         // Lagged publication without draining the memory pipeline: vmcnt retires in issue order, so once the
         // slot loads issued during iteration i-1 have been consumed (all of them were, just above), every store
@@ -556,6 +609,23 @@ int sor_probe_dpp(papof_handle* h) {
     for (int l = 1; l < 64; l++) ok = ok && host[l] == l;             // lane l sees lane l-1 (value l-1+1)
     for (int l = 0; l < 63; l++) ok = ok && host[64 + l] == l + 2;    // lane l sees lane l+1 (value l+1+1)
     h->use_dpp = ok;
+    if (std::getenv("PAPOF_PROBE")) {
+        unsigned long long* dt = nullptr;
+        double* sink = nullptr;
+        if (hipMalloc((void**)&dt, 16) == hipSuccess && hipMalloc((void**)&sink, 64 * 8) == hipSuccess) {
+            for (int rep = 0; rep < 3; rep++) {
+                const int n = 200000;
+                hipLaunchKernelGGL(k_alu_probe, dim3(1), dim3(kLanes), 0, h->stream, dt, sink, n, 1.0 + rep);
+                unsigned long long t[2] = {0, 0};
+                hipMemcpyAsync(t, dt, 16, hipMemcpyDeviceToHost, h->stream);
+                hipStreamSynchronize(h->stream);
+                std::fprintf(stderr, "[papof probe] dpp=%d  %d steps: %.1f shader cycles/step, %.4f us/step, clock %.0f MHz\n",
+                             (int)ok, n, (double)t[0] / n, (double)t[1] * 0.01 / n, (double)t[0] / ((double)t[1] * 0.01));
+            }
+        }
+        hipFree(dt);
+        hipFree(sink);
+    }
     if (const char* s = std::getenv("PAPOF_SOR_XLANE")) {
         if (std::strcmp(s, "shfl") == 0) h->use_dpp = false;
     }
