@@ -89,57 +89,80 @@ def main():
     ap.add_argument("--schedule", default="cfg4", choices=sorted(SCHEDULES))
     ap.add_argument("--mode", default="exact", choices=sorted(MODES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1")
+    ap.add_argument("--simulate-step-ms", type=float, default=0.0,
+                    help="CPU-only rehearsal of the N>1 protocol (tests): a step sleeps (rank+1) x this long instead "
+                         "of running the GPU path; the printed value is meaningless")
     args = ap.parse_args()
+    simulate = args.simulate_step_ms > 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    use_cuda = not simulate
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if use_cuda:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
-    from papteam_opticalflow_amd import Papof, default_params
-    gpu = Papof(local_rank)
-    a, b, data_desc = load_frames(args.res)
-    h, w, c = a.shape
     sched, mode = SCHEDULES[args.schedule], MODES[args.mode]
-    P = default_params(n_outer=sched[0], n_outer_per_level=sched[1], n_sor=sched[2], n_sor_per_level=sched[3],
-                       sor_mode=mode, omega=1.8 if mode != 2 else 1.0, phase_timing=0)
-    d1, d2 = gpu.dev_alloc(a.nbytes), gpu.dev_alloc(b.nbytes)
-    dvx, dvy, dwp = gpu.dev_alloc(h * w * 8), gpu.dev_alloc(h * w * 8), gpu.dev_alloc(a.nbytes)
-    gpu.dev_upload(d1, a)  # inputs resident in HBM before the timed region
-    gpu.dev_upload(d2, b)
+    if simulate:
+        gpu = None
+        h, w = {"240": (135, 240), "480": (270, 480), "960": (540, 960), "1920": (1080, 1920)}[args.res]
+        c, data_desc = 3, "none (protocol rehearsal)"
+
+        def one_step():
+            time.sleep(args.simulate_step_ms * 1e-3 * (rank + 1))
+            return [0.0] * 10
+    else:
+        from papteam_opticalflow_amd import Papof, default_params
+        gpu = Papof(local_rank)
+        a, b, data_desc = load_frames(args.res)
+        h, w, c = a.shape
+        P = default_params(n_outer=sched[0], n_outer_per_level=sched[1], n_sor=sched[2], n_sor_per_level=sched[3],
+                           sor_mode=mode, omega=1.8 if mode != 2 else 1.0, phase_timing=0)
+        d1, d2 = gpu.dev_alloc(a.nbytes), gpu.dev_alloc(b.nbytes)
+        dvx, dvy, dwp = gpu.dev_alloc(h * w * 8), gpu.dev_alloc(h * w * 8), gpu.dev_alloc(a.nbytes)
+        gpu.dev_upload(d1, a)  # inputs resident in HBM before the timed region
+        gpu.dev_upload(d2, b)
+
+        def one_step():  # returns after the library's stream has drained
+            return gpu.flow_device(d1, d2, h, w, c, args.levels, P, dvx, dvy, dwp)
 
     def sync_all():
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
+            if use_cuda:
+                import torch
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if use_cuda:
+                import torch
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        gpu.flow_device(d1, d2, h, w, c, args.levels, P, dvx, dvy, dwp)
+        one_step()
     sync_all()
     t0 = time.perf_counter()
     sor_sec = 0.0
     for _ in range(args.steps):
-        t = gpu.flow_device(d1, d2, h, w, c, args.levels, P, dvx, dvy, dwp)  # returns after its stream drained
-        sor_sec += t[6]
+        sor_sec += one_step()[6]
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if use_cuda else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)  # the slowest rank defines the job's time
         elapsed = float(tt.item())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * (h * w / 1e6) / (elapsed / args.steps)
-        dims = level_dims(gpu, h, w, args.levels)
+        dims = level_dims(gpu, h, w, args.levels) if gpu is not None else [(w, h)] * args.levels
         updates = sum(lw * lh * (sched[0] + k * sched[1]) * (sched[2] + k * sched[3]) for k, (lw, lh) in enumerate(dims))
         launches = sum(sched[0] + k * sched[1] for k in range(args.levels)) * (1 if mode == 0 else 0)
         sor_step = sor_sec / args.steps
@@ -159,7 +182,7 @@ def main():
             key = {("1920", "cfg4", 5): "cfg4_1920_L5", ("1920", "reference", 5): "e2e_1920_L5",
                    ("480", "cfg4", 5): "cfg4_480_L5", ("960", "reference", 5): "e2e_960_L5"}.get(
                        (args.res, args.schedule, args.levels))
-            if key and mode == 0:
+            if key and mode == 0 and gpu is not None:
                 vx, vy = np.zeros((h, w)), np.zeros((h, w))
                 gpu.dev_download(vx, dvx)
                 gpu.dev_download(vy, dvy)
@@ -184,16 +207,17 @@ def main():
                          "avg_launch_ms": round(sor_step * 1e3 / launches, 4) if launches else None,
                          "sor_ms_per_step": round(sor_step * 1e3, 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not simulate:
             kind, dt = cpu_baseline(a, b, args.levels, sched, mode)
             out["cpu_baseline"] = {"value": round(h * w / 1e6 / dt, 5), "unit": "Mpix/s", "cores": 1, "kind": kind,
                                    "sample": "the same %dx%d pair and schedule, one full solve (%.1f s), single "
                                              "thread (the reference Serial path is single-threaded)" % (w, h, dt),
                                    "host_cpus": os.cpu_count()}
         print(json.dumps(out), flush=True)
-    for p in (d1, d2, dvx, dvy, dwp):
-        gpu.dev_free(p)
-    gpu.close()
+    if gpu is not None:
+        for p in (d1, d2, dvx, dvy, dwp):
+            gpu.dev_free(p)
+        gpu.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,172 +1,181 @@
-"""Lane-level model of the exact-order SOR kernel (papteam_opticalflow_amd/csrc/sor_exact.hip).
+"""Lane-level model of the exact-order SOR kernel `k_sor_exact<R>` (papteam_opticalflow_amd/csrc/sor.hip).
 
-The kernel keeps the reference's in-place lexicographic sweep order (src/OpticalFlow.cpp:458-505)
-while running thousands of cells concurrently.  Work decomposition:
+The kernel keeps the reference's in-place lexicographic sweep order (src/OpticalFlow.cpp:458-505) while running
+thousands of cells concurrently.  Work decomposition, as in the HIP code:
 
-* the image is cut into BANDS of 64 rows; one wavefront (64 lanes, lane r = row r of the band)
-  executes one TASK = (band b, sweep k);
-* at STEP s lane r updates column j = s - r  ("skewed" march: the lane above is one column ahead),
-  so a task takes NS = W + 63 steps;
-* per-plane storage is SKEWED per band: element (row r, column j) of band b lives at
-  ((b*NS + (j + r))*64 + r), so at step s the 64 lanes touch 64 consecutive doubles;
-* left neighbour (new)  = the lane's own previous result (register)
-  up   neighbour (new)  = previous result of lane r-1 (cross-lane shift); lane 0 reads band b-1's row 63
-  right neighbour (old) = loaded from the skewed plane at step s+1 (it becomes the next centre)
-  down neighbour (old)  = lane r+1's pending centre value (cross-lane shift); lane 63 reads band b+1's row 0
-* tasks are independent wavefronts synchronised only by per-task progress counters:
-  before running steps [s0, s1) task (b,k) needs
-      prog[b  ][k-1] >= min(NS, s1 + 1)     (centre/right old values of its own band)
-      prog[b-1][k  ] >= min(NS, s1 + 63)    (row 63 of the band above, this sweep)
-      prog[b+1][k-1] >= min(NS, s1 - 63)    (row 0 of the band below, previous sweep)
-  and publishes prog[b][k] = s1 afterwards.
+* the image is cut into BANDS of 62 rows; one wavefront executes one TASK = (band b, sweep k); lanes 1..62 carry
+  the band's rows, lane 0 / lane 63 are GHOST lanes standing for the last row of band b-1 / first row of band b+1;
+* at STEP s lane l works on column j = s - l (the lane above is one column ahead), NS = W + 63 steps per task;
+* operands live in per-band SKEWED planes: cell (lane l, column j) of band b at position (b, j + l, l), every
+  position that is not a real cell holds 0.0, so borders need no predicates;
+* left-new = the lane's own previous result; up-new = previous result of lane l-1; down-old = the pending centre of
+  lane l+1; right-old is LOADED (it becomes the next centre).  Ghost lanes load the neighbour band's cells
+  (band b-1 lane 62 at position +62, band b+1 lane 1 at position -62), pass the value through and never store;
+* every load is issued R steps before its use (software pipeline); before iteration i (steps [iR, iR+R)) issues its
+  loads -- which are for steps < (i+2)R =: e -- the task needs
+      prog[k-1][b]   >= min(NS, e + 1)     own band, previous sweep (centre / right-old)
+      prog[k][b-1]   >= min(NS, e + 63)    band above, this sweep   (ghost lane 0)
+      prog[k-1][b+1] >= min(NS, e - 60)    band below, previous sweep (ghost lane 63)
+  and at the end of iteration i >= 1 it publishes prog[k][b] = iR (lagging: only stores proven complete), finally NS.
 
-`simulate()` executes exactly that dataflow with numpy (one vector op per wave instruction, same
-operation order as the kernel, no FMA) under a RANDOM task scheduler that honours only the
-progress conditions above, so a too-weak condition shows up as a mismatch with the oracle.
+`simulate()` executes exactly that dataflow with numpy (same operation order, no FMA) under a RANDOM task scheduler
+that honours only the progress conditions above, with loads really taken R steps early and publications really
+lagging, so a too-weak condition shows up as a mismatch with the oracle.
 """
 import numpy as np
 
 LANES = 64
+ROWS = LANES - 2
 
 
-def skew_dims(h, w):
-    nb = (h + LANES - 1) // LANES
+def skew_dims(h, w, r=8):
+    nb = (h + ROWS - 1) // ROWS
     ns = w + LANES - 1
-    return nb, ns
+    nsp = (ns + 31) // 32 * 32 + 64
+    return nb, ns, nsp
 
 
-def to_skew(plane):
+def to_skew(plane, r=8):
     h, w = plane.shape
-    nb, ns = skew_dims(h, w)
-    out = np.zeros((nb, ns, LANES))
+    nb, ns, nsp = skew_dims(h, w, r)
+    out = np.zeros((nb, nsp + 1, LANES))
     for i in range(h):
-        b, r = divmod(i, LANES)
-        out[b, r:r + w, r] = plane[i]
+        b, l = divmod(i, ROWS)
+        l += 1
+        out[b, l:l + w, l] = plane[i]
     return out
 
 
 def from_skew(sk, h, w):
     out = np.zeros((h, w))
     for i in range(h):
-        b, r = divmod(i, LANES)
-        out[i] = sk[b, r:r + w, r]
+        b, l = divmod(i, ROWS)
+        l += 1
+        out[i] = sk[b, l:l + w, l]
     return out
 
 
-def shift_up(x, fill0):
-    """lane r receives lane r-1's value; lane 0 receives fill0."""
-    y = np.empty_like(x)
+def shift_up(x):
+    """lane l receives lane l-1's value (lane 0: unspecified -> 0)."""
+    y = np.zeros_like(x)
     y[1:] = x[:-1]
-    y[0] = fill0
     return y
 
 
-def shift_down(x, fill63):
-    y = np.empty_like(x)
+def shift_down(x):
+    y = np.zeros_like(x)
     y[:-1] = x[1:]
-    y[-1] = fill63
     return y
 
 
 class Task:
-    def __init__(self, b, k):
-        self.b, self.k, self.s = b, k, 0
+    def __init__(self, b, k, r):
+        self.b, self.k, self.i = b, k, -1  # -1: prologue (initial fill) not done yet
         z = np.zeros(LANES)
-        self.duL, self.dvL, self.phiL = z.copy(), z.copy(), z.copy()
-        self.duC, self.dvC = z.copy(), z.copy()
+        self.duL, self.dvL, self.phiL, self.duC, self.dvC = z.copy(), z.copy(), z.copy(), z.copy(), z.copy()
+        self.slots = [None] * r
+        self.pending_pub = 0
 
 
-def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, chunk=16, seed=0):
-    """a1 = omega/(imdx2 + alpha*0.05 + coeff), a2 likewise: computed by the caller exactly as the
-    system-assembly kernel does.  Returns du, dv (H x W) after n_sor sweeps."""
+def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0):
+    """a1 = omega/(imdx2 + alpha*0.05 + coeff), a2 likewise (see sor_coefficients).  Returns du, dv (H x W)."""
     h, w = phi.shape
-    nb, ns = skew_dims(h, w)
-    S = {n: to_skew(p) for n, p in dict(phi=phi, imdxy=imdxy, a1=a1, a2=a2, b1=b1, b2=b2).items()}
-    du = np.full((nb, ns + 1, LANES), np.nan)  # NaN poison: any read of a not-yet-written cell shows up
-    dv = np.full((nb, ns + 1, LANES), np.nan)
+    nb, ns, nsp = skew_dims(h, w, r)
+    P = {n: to_skew(p, r) for n, p in dict(phi=phi, xy=imdxy, a1=a1, a2=a2, b1=b1, b2=b2).items()}
+    du = np.zeros((nb, nsp + 1, LANES))  # memset before every solve
+    dv = np.zeros((nb, nsp + 1, LANES))
     prog = np.zeros((nb, n_sor), dtype=np.int64)
-    nalpha, om1 = -alpha, 1 - omega
+    nalpha = -alpha
+    om1 = np.full(LANES, 1 - omega)
+    om1[0] = om1[63] = 1.0
     lane = np.arange(LANES)
+    real = (lane >= 1) & (lane <= 62)
+    n_iter = (ns + r - 1) // r
     rng = np.random.default_rng(seed)
-    tasks = [Task(b, k) for k in range(n_sor) for b in range(nb)]
-    pending = list(tasks)
+
+    def covered(b, k, e):
+        ok = True
+        if k > 0:
+            ok = ok and prog[b, k - 1] >= min(ns, e + 1)
+        if b > 0:
+            ok = ok and prog[b - 1, k] >= min(ns, e + 63)
+        if k > 0 and b + 1 < nb:
+            ok = ok and prog[b + 1, k - 1] >= min(ns, max(0, e - 60))
+        return ok
+
+    def rd(arr, b, pos, ln):
+        """one cell of a skewed plane; positions outside the band's own range read padding (0)"""
+        if b < 0 or b >= nb or pos < 0 or pos > nsp:
+            return 0.0
+        return arr[b, pos, ln]
+
+    def load_pd(arr, b, pos):
+        """the (du|dv) vector a task of band b loads for skew position `pos`"""
+        v = np.where(real, arr[b, min(pos, nsp), :] if 0 <= pos <= nsp else 0.0, 0.0)
+        v[0] = rd(arr, b - 1, pos + 62, 62) if b > 0 else 0.0
+        v[63] = rd(arr, b + 1, pos - 62, 1) if b + 1 < nb else 0.0
+        return v
+
+    def load_slot(b, s):
+        g = lambda n: np.where(real, P[n][b, s, :] if s <= nsp else 0.0, 0.0)
+        phi_v = g("phi")
+        phi_v[0] = rd(P["phi"], b - 1, s + 62, 62) if b > 0 else 0.0
+        return dict(phi=phi_v, xy=g("xy"), a1=g("a1"), a2=g("a2"), b1=g("b1"), b2=g("b2"),
+                    duR=load_pd(du, b, s + 1), dvR=load_pd(dv, b, s + 1))
+
+    pending = [Task(b, k, r) for k in range(n_sor) for b in range(nb)]
     while pending:
-        order = rng.permutation(len(pending))
         ran = False
-        for ti in order:
+        for ti in rng.permutation(len(pending)):
             t = pending[ti]
             b, k = t.b, t.k
-            s1 = min(ns, t.s + chunk)
-            ok = True
-            if k > 0 and prog[b, k - 1] < min(ns, s1 + 1):
-                ok = False
-            if b > 0 and prog[b - 1, k] < min(ns, s1 + 63):
-                ok = False
-            if k > 0 and b + 1 < nb and prog[b + 1, k - 1] < min(ns, s1 - 63):
-                ok = False
-            if not ok:
+            if t.i < 0:  # prologue: needs coverage of steps < 2R, then the first centre and the first R slots
+                if not covered(b, k, 2 * r):
+                    continue
+                t.duC, t.dvC = load_pd(du, b, 0), load_pd(dv, b, 0)
+                for s in range(r):
+                    t.slots[s] = load_slot(b, s)
+                t.i = 0
+                ran = True
+                break
+            i = t.i
+            if i > 0 and not covered(b, k, (i + 2) * r):
                 continue
             ran = True
-            row = b * LANES + lane
-            if t.s == 0 and k > 0:  # centre of the very first column = skew position 0 (lane 0 only matters)
-                t.duC = np.where(lane == 0, du[b, 0, :], 0.0)
-                t.dvC = np.where(lane == 0, dv[b, 0, :], 0.0)
-            for s in range(t.s, s1):
-                j = s - lane
-                valid = (j >= 0) & (j < w) & (row < h)
-                ld = lambda a: np.where(valid, a[b, s, :], 0.0)
-                phiC, xy, A1, A2, B1, B2 = (ld(S[n]) for n in ("phi", "imdxy", "a1", "a2", "b1", "b2"))
-                # right-old = cell (r, j+1) of sweep k-1, skew position s+1
-                rvalid = (j + 1 >= 0) & (j + 1 < w) & (row < h)
-                if k > 0:
-                    duR = np.where(rvalid, du[b, s + 1, :], 0.0)
-                    dvR = np.where(rvalid, dv[b, s + 1, :], 0.0)
-                else:
-                    duR = np.zeros(LANES)
-                    dvR = np.zeros(LANES)
-                # halos
-                upu = upv = upphi = 0.0
-                if b > 0 and 0 <= s < w:  # lane 0, column j = s ; band above, row 63 -> skew position s+63
-                    upu, upv = du[b - 1, s + 63, 63], dv[b - 1, s + 63, 63]
-                    upphi = S["phi"][b - 1, s + 63, 63]
-                dnu = dnv = 0.0
-                j63 = s - 63
-                if k > 0 and b + 1 < nb and 0 <= j63 < w and (b + 1) * LANES < h:
-                    dnu, dnv = du[b + 1, j63, 0], dv[b + 1, j63, 0]
-                duU, dvU, phiU = shift_up(t.duL, upu), shift_up(t.dvL, upv), shift_up(t.phiL, upphi)
-                # down-old = cell (r+1, j) of sweep k-1: lane r+1 sits at column j-1, so it is ITS right-old value
-                duD, dvD = shift_down(duR, dnu), shift_down(dvR, dnv)
-                wL = t.phiL
-                wR = np.where(j < w - 1, phiC, 0.0)
-                wU = np.where(row > 0, phiU, 0.0)
-                wD = np.where(row < h - 1, phiC, 0.0)
-                s1_ = wL * t.duL
-                s2_ = wL * t.dvL
-                s1_ = s1_ + wR * duR
-                s2_ = s2_ + wR * dvR
-                s1_ = s1_ + wU * duU
-                s2_ = s2_ + wU * dvU
-                s1_ = s1_ + wD * duD
-                s2_ = s2_ + wD * dvD
-                s1_ = s1_ * nalpha
-                s2_ = s2_ * nalpha
-                s1_ = s1_ + xy * t.dvC
-                duN = om1 * t.duC + A1 * (B1 - s1_)
-                s2_ = s2_ + xy * duN
-                dvN = om1 * t.dvC + A2 * (B2 - s2_)
-                duN = np.where(valid, duN, 0.0)
-                dvN = np.where(valid, dvN, 0.0)
-                du[b, s, :] = np.where(valid, duN, du[b, s, :])
-                dv[b, s, :] = np.where(valid, dvN, dv[b, s, :])
-                t.duL, t.dvL, t.phiL = duN, dvN, phiC
-                t.duC, t.dvC = duR, dvR
-            t.s = s1
-            prog[b, k] = s1
-            if s1 == ns:
+            for tt in range(r):
+                s = i * r + tt
+                c = t.slots[tt]
+                duU, dvU, phiU = shift_up(t.duL), shift_up(t.dvL), shift_up(t.phiL)
+                duD, dvD = shift_down(c["duR"]), shift_down(c["dvR"])
+                s1 = t.phiL * t.duL
+                s2 = t.phiL * t.dvL
+                s1 = s1 + c["phi"] * c["duR"]
+                s2 = s2 + c["phi"] * c["dvR"]
+                s1 = s1 + phiU * duU
+                s2 = s2 + phiU * dvU
+                s1 = s1 + c["phi"] * duD
+                s2 = s2 + c["phi"] * dvD
+                s1 = s1 * nalpha
+                s2 = s2 * nalpha
+                s1 = s1 + c["xy"] * t.dvC
+                duN = om1 * t.duC + c["a1"] * (c["b1"] - s1)
+                s2 = s2 + c["xy"] * duN
+                dvN = om1 * t.dvC + c["a2"] * (c["b2"] - s2)
+                if s <= nsp:
+                    du[b, s, :] = np.where(real, duN, du[b, s, :])  # ghost lanes never store
+                    dv[b, s, :] = np.where(real, dvN, dv[b, s, :])
+                t.duL, t.dvL, t.phiL = duN, dvN, c["phi"]
+                t.duC, t.dvC = c["duR"], c["dvR"]
+                t.slots[tt] = load_slot(b, s + r)  # refill R steps ahead: reads memory NOW
+            if i > 0:
+                prog[b, k] = min(ns, i * r)  # lagging publication
+            t.i += 1
+            if t.i == n_iter:
+                prog[b, k] = ns
                 pending.pop(ti)
             break
         assert ran, "deadlock in the task graph"
-    return from_skew(du[:, :ns], h, w), from_skew(dv[:, :ns], h, w)
+    return from_skew(du, h, w), from_skew(dv, h, w)
 
 
 def sor_coefficients(phi, imdx2, imdy2, alpha, omega):

@@ -18,13 +18,13 @@ def _planes(h, w, seed):
     return phi, imdxy, imdx2, imdy2, r1, r2
 
 
-@pytest.mark.parametrize("h,w,n_sor,chunk", [(70, 50, 4, 16), (130, 37, 3, 8), (64, 20, 3, 16), (1, 5, 3, 4),
-                                              (5, 1, 3, 16), (129, 3, 2, 5), (42, 75, 5, 32)])
+@pytest.mark.parametrize("h,w,n_sor,chunk", [(70, 50, 4, 8), (130, 37, 3, 8), (64, 20, 3, 4), (1, 5, 3, 4),
+                                              (5, 1, 3, 8), (129, 3, 2, 6), (42, 75, 5, 9), (190, 90, 4, 8)])
 def test_wave_schedule_is_bit_exact(oracle, h, w, n_sor, chunk):
     alpha, omega = 0.012, 1.8
     phi, imdxy, imdx2, imdy2, r1, r2 = _planes(h, w, h * 1000 + w)
     a1, a2 = sim.sor_coefficients(phi, imdx2, imdy2, alpha, omega)
-    du, dv = sim.simulate(phi, imdxy, a1, a2, r1, r2, n_sor, alpha, omega, chunk=chunk, seed=w)
+    du, dv = sim.simulate(phi, imdxy, a1, a2, r1, r2, n_sor, alpha, omega, r=chunk, seed=w)
     eu, ev = oracle.sor(phi, imdxy, imdx2, imdy2, r1, r2, n_sor, alpha=alpha, omega=omega, mode=0)
     assert np.array_equal(du, eu)
     assert np.array_equal(dv, ev)
