@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--schedule", default="cfg4", choices=sorted(SCHEDULES))
     ap.add_argument("--mode", default="exact", choices=sorted(MODES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pairs", type=int, default=1,
+                    help="frame pairs solved concurrently per GPU (one handle + stream + host thread each); a step "
+                         "is then one solve of EVERY pair and value counts all of them")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1")
     ap.add_argument("--simulate-step-ms", type=float, default=0.0,
                     help="CPU-only rehearsal of the N>1 protocol (tests): a step sleeps (rank+1) x this long instead "
@@ -130,9 +133,26 @@ def main():
         dvx, dvy, dwp = gpu.dev_alloc(h * w * 8), gpu.dev_alloc(h * w * 8), gpu.dev_alloc(a.nbytes)
         gpu.dev_upload(d1, a)  # inputs resident in HBM before the timed region
         gpu.dev_upload(d2, b)
+        extra = []  # further concurrent pairs: own handle (arena + stream) and own output buffers each
+        for _ in range(args.pairs - 1):
+            g2 = Papof(local_rank)
+            extra.append((g2, g2.dev_alloc(h * w * 8), g2.dev_alloc(h * w * 8), g2.dev_alloc(a.nbytes)))
 
-        def one_step():  # returns after the library's stream has drained
-            return gpu.flow_device(d1, d2, h, w, c, args.levels, P, dvx, dvy, dwp)
+        def one_step():  # returns after every stream has drained
+            if not extra:
+                return gpu.flow_device(d1, d2, h, w, c, args.levels, P, dvx, dvy, dwp)
+            import threading
+            res = [None] * (1 + len(extra))
+
+            def run(i, g, ox, oy, ow):
+                res[i] = g.flow_device(d1, d2, h, w, c, args.levels, P, ox, oy, ow)
+            th = [threading.Thread(target=run, args=(i + 1,) + e) for i, e in enumerate(extra)]
+            for t_ in th:
+                t_.start()
+            run(0, gpu, dvx, dvy, dwp)
+            for t_ in th:
+                t_.join()
+            return res[0]
 
     def sync_all():
         if dist is not None:
@@ -161,7 +181,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * (h * w / 1e6) / (elapsed / args.steps)
+        value = world * args.pairs * (h * w / 1e6) / (elapsed / args.steps)
         dims = level_dims(gpu, h, w, args.levels) if gpu is not None else [(w, h)] * args.levels
         updates = sum(lw * lh * (sched[0] + k * sched[1]) * (sched[2] + k * sched[3]) for k, (lw, lh) in enumerate(dims))
         launches = sum(sched[0] + k * sched[1] for k in range(args.levels)) * (1 if mode == 0 else 0)
@@ -198,6 +218,7 @@ def main():
             "config": {"workload": "%dx%d frame pair, %d-level pyramid, schedule %s (outer %d+%dk, SOR %d+%dk), "
                                    "%s-order SOR" % (w, h, args.levels, args.schedule, sched[0], sched[1], sched[2],
                                                      sched[3], args.mode),
+                       "pairs_in_flight_per_gpu": args.pairs,
                        "parallelism": "replicas: one independent frame pair per GPU" if world > 1 else "1 GPU"},
             "max_abs_duv_vs_reference": parity,
             "roofline": {"bound": "hbm", "kernel": "k_sor_exact" if mode == 0 else "k_sor_" + args.mode,

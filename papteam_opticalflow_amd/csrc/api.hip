@@ -406,7 +406,8 @@ int papof_create(int device, papof_handle** out) {
         delete h;
         return PAPOF_ENODEVICE;
     }
-    if (const char* cs = std::getenv("PAPOF_SOR_DEPTH")) h->sor_depth = std::max(8, std::atoi(cs));
+    if (const char* cs = std::getenv("PAPOF_SOR_DEPTH")) h->sor_depth = std::max(4, std::atoi(cs));
+    if (const char* cs = std::getenv("PAPOF_SOR_SEGS")) h->sor_segments = std::max(1, std::atoi(cs));
     int rc = sor_probe_dpp(h);
     if (rc != PAPOF_OK) {
         papof_destroy(h);

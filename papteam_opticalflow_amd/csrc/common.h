@@ -115,6 +115,7 @@ struct papof_handle {
     size_t events_used = 0;
     int cu_count = 0;
     bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
+    int sor_segments = 1;            // publication / coverage-check segments per R steps
     int sor_depth = 8;               // software-pipeline depth R (steps) of the exact-order SOR kernel
 };
 

@@ -274,6 +274,21 @@ struct Unroll<R, -1, DPP> {
     static __device__ __forceinline__ void fill(const Task&, const LaneOffs&, Slots<R>&) {}
 };
 
+// steps t0 .. t1-1 of the unrolled iteration
+template <int R, int t0, int t1, bool DPP>
+struct Seg {
+    static __device__ __forceinline__ void run(const ExactArgs& A, const Task& T, const LaneOffs& L, double om1,
+                                               int s0, Slots<R>& c, State& S) {
+        step<R, t0, DPP>(A, T, L, om1, s0 + t0, c, S);
+        Seg<R, t0 + 1, t1, DPP>::run(A, T, L, om1, s0, c, S);
+    }
+};
+template <int R, int t1, bool DPP>
+struct Seg<R, t1, t1, DPP> {
+    static __device__ __forceinline__ void run(const ExactArgs&, const Task&, const LaneOffs&, double, int, Slots<R>&,
+                                               State&) {}
+};
+
 // Progress of the three producers of a task, polled together (a missing producer reads as "finished").
 struct Polls {
     unsigned own, up, dn;
@@ -311,8 +326,46 @@ __device__ __forceinline__ bool wait_covered(const ExactArgs& A, Polls& pl, unsi
     return true;
 }
 
-template <int R, bool DPP>
+// One segment (H = R/G steps) of an iteration: wait for coverage of the loads it will issue, prefetch the next poll,
+// run the steps, publish what is proven complete.
+template <int R, int G, int g, bool DPP>
+struct Segments {
+    static __device__ __forceinline__ bool run(const ExactArgs& A, const Task& T, const LaneOffs& L, double om1, int i,
+                                               Slots<R>& c, State& S, Polls& pl, unsigned* my_prog, unsigned* p_own,
+                                               unsigned* p_up, unsigned* p_dn, bool prev, bool has_up, bool has_dn,
+                                               bool lane0) {
+        constexpr int H = R / G;
+        const int s_lo = i * R + g * H, s_hi = s_lo + H;
+        // loads issued by steps [s_lo, s_hi) are those of steps [s_lo + R, s_hi + R)
+        if ((i > 0 || g > 0) && !wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, s_hi + R)) return false;
+        const Polls pn = poll(p_own, p_up, p_dn, prev, has_up, has_dn);  // poll for the next segment
+        Seg<R, g * H, (g + 1) * H, DPP>::run(A, T, L, om1, i * R, c, S);
+        pl = pn;
+        // Lagged publication without draining the memory pipeline: vmcnt retires in issue order and the slot consumed
+        // by step s was loaded during step s - R *after* that step's store, so having consumed the slot of step
+        // s_hi - 1 proves every store of steps <= s_hi - 1 - R complete.  The asm ties the counter store to the last
+        // consumed operand so the compiler cannot hoist it above that wait.
+        if (s_hi - R > 0) {
+            asm volatile("" ::"v"(S.duL), "v"(S.dvL) : "memory");
+            if (lane0)
+                __hip_atomic_store(my_prog, (unsigned)min(A.ns, s_hi - R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return Segments<R, G, g + 1, DPP>::run(A, T, L, om1, i, c, S, pl, my_prog, p_own, p_up, p_dn, prev, has_up,
+                                               has_dn, lane0);
+    }
+};
+template <int R, int G, bool DPP>
+struct Segments<R, G, G, DPP> {
+    static __device__ __forceinline__ bool run(const ExactArgs&, const Task&, const LaneOffs&, double, int, Slots<R>&,
+                                               State&, Polls&, unsigned*, unsigned*, unsigned*, unsigned*, bool, bool,
+                                               bool, bool) {
+        return true;
+    }
+};
+
+template <int R, int G, bool DPP>
 __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
+    static_assert(R % G == 0, "segments must divide the pipeline depth");
     const unsigned lane = threadIdx.x, lane16 = lane * 16u;
     const int task = blockIdx.x;
     const int k = task / A.nb, b = task - k * A.nb;
@@ -358,8 +411,9 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     S.duL = S.dvL = S.phiL = 0.0;
     Slots<R> c;
 
-    // Before iteration i every load it issues (slots of iteration i + 1) must be covered: producers' progress for
-    // steps < (i + 2) * R.  The polls themselves are prefetched one iteration ahead.
+    // Every load must be covered by the producers' published progress before it is issued: the prologue loads steps
+    // < R (+ the refills of the first segment), each segment checks its own refills (Segments::run).  The polls
+    // themselves are prefetched one segment ahead.
     Polls pl = poll(p_own, p_up, p_dn, prev, has_up, has_dn);
     if (!wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, 2 * R)) return;
     {  // centre of the first cells: the (du, dv) one skew position before the step-0 right-old
@@ -370,21 +424,10 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     }
     Unroll<R, R - 1, DPP>::fill(T, L, c);
 
-    for (int i = 0; i < n_iter; ++i) {
-        if (i > 0 && !wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, (i + 2) * R)) return;
-        const Polls pn = poll(p_own, p_up, p_dn, prev, has_up, has_dn);  // poll for iteration i + 1
-        Unroll<R, R - 1, DPP>::run(A, T, L, om1, i * R, c, S);
-        pl = pn;
-        // Lagged publication without draining the memory pipeline: vmcnt retires in issue order, so once the
-        // slot loads issued during iteration i-1 have been consumed (all of them were, just above), every store
-        // issued before them -- all of iterations < i -- has completed.  The asm ties the counter store to the
-        // last consumed operand so the compiler cannot hoist it above that wait.
-        if (i > 0) {
-            asm volatile("" ::"v"(S.duL), "v"(S.dvL) : "memory");
-            if (lane == 0)
-                __hip_atomic_store(my_prog, (unsigned)min(ns, i * R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    for (int i = 0; i < n_iter; ++i)
+        if (!Segments<R, G, 0, DPP>::run(A, T, L, om1, i, c, S, pl, my_prog, p_own, p_up, p_dn, prev, has_up, has_dn,
+                                         lane == 0))
+            return;
     // final publication: every store of this wave has left the CU before the counter moves (guide G16/R1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(my_prog, (unsigned)ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -498,17 +541,30 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         // du = dv = 0 before the first sweep (src/OpticalFlow.cpp:452-453); also clears the ghost-lane mirrors
         PAPOF_HIP(hipMemsetAsync(sp.du, 0, (sd.n + kLanes) * 16, h->stream));
         const dim3 grid(sd.nb * n_sor), block(kLanes);
-        const int R = h->sor_depth;
+        const int R = h->sor_depth, G = h->sor_segments;
+#define PAPOF_LAUNCH_EXACT(RR, GG, DD) hipLaunchKernelGGL((k_sor_exact<RR, GG, DD>), grid, block, 0, h->stream, A)
         if (!h->use_dpp)
-            hipLaunchKernelGGL((k_sor_exact<8, false>), grid, block, 0, h->stream, A);
+            PAPOF_LAUNCH_EXACT(8, 2, false);
         else if (R <= 4)
-            hipLaunchKernelGGL((k_sor_exact<4, true>), grid, block, 0, h->stream, A);
-        else if (R <= 6)
-            hipLaunchKernelGGL((k_sor_exact<6, true>), grid, block, 0, h->stream, A);
-        else if (R <= 8)
-            hipLaunchKernelGGL((k_sor_exact<8, true>), grid, block, 0, h->stream, A);
-        else
-            hipLaunchKernelGGL((k_sor_exact<9, true>), grid, block, 0, h->stream, A);
+            PAPOF_LAUNCH_EXACT(4, 2, true);
+        else if (R <= 6) {
+            if (G >= 3)
+                PAPOF_LAUNCH_EXACT(6, 3, true);
+            else
+                PAPOF_LAUNCH_EXACT(6, 2, true);
+        } else if (R <= 8) {
+            if (G >= 4)
+                PAPOF_LAUNCH_EXACT(8, 4, true);
+            else if (G >= 2)
+                PAPOF_LAUNCH_EXACT(8, 2, true);
+            else
+                PAPOF_LAUNCH_EXACT(8, 1, true);
+        } else if (R <= 10) {
+            PAPOF_LAUNCH_EXACT(10, 1, true);
+        } else {
+            PAPOF_LAUNCH_EXACT(12, 1, true);
+        }
+#undef PAPOF_LAUNCH_EXACT
         PAPOF_HIP(hipGetLastError());
         return PAPOF_OK;
     }
@@ -613,9 +669,11 @@ int sor_probe_dpp(papof_handle* h) {
         unsigned long long* dt = nullptr;
         double* sink = nullptr;
         if (hipMalloc((void**)&dt, 16) == hipSuccess && hipMalloc((void**)&sink, 64 * 8) == hipSuccess) {
-            for (int rep = 0; rep < 3; rep++) {
+            for (int rep = 0; rep < 4; rep++) {
                 const int n = 200000;
-                hipLaunchKernelGGL(k_alu_probe, dim3(1), dim3(kLanes), 0, h->stream, dt, sink, n, 1.0 + rep);
+                const int lanes = rep == 0 ? 64 : (rep == 1 ? 48 : (rep == 2 ? 32 : 16));
+                std::fprintf(stderr, "[papof probe] active lanes %d: ", lanes);
+                hipLaunchKernelGGL(k_alu_probe, dim3(1), dim3(lanes), 0, h->stream, dt, sink, n, 1.0 + rep);
                 unsigned long long t[2] = {0, 0};
                 hipMemcpyAsync(t, dt, 16, hipMemcpyDeviceToHost, h->stream);
                 hipStreamSynchronize(h->stream);

@@ -11,12 +11,13 @@ thousands of cells concurrently.  Work decomposition, as in the H
 * left-new = the lane's own previous result; up-new = previous result of lane l-1; down-old = the pending centre of
   lane l+1; right-old is LOADED (it becomes the next centre).  Ghost lanes load the neighbour band's cells
   (band b-1 lane 62 at position +62, band b+1 lane 1 at position -62), pass the value through and never store;
-* every load is issued R steps before its use (software pipeline); before iteration i (steps [iR, iR+R)) issues its
-  loads -- which are for steps < (i+2)R =: e -- the task needs
+* every load is issued R steps before its use (software pipeline), in SEGMENTS of H = R/G steps; before a segment
+  [s_lo, s_hi) issues its loads -- which are for steps < s_hi + R =: e -- the task needs
       prog[k-1][b]   >= min(NS, e + 1)     own band, previous sweep (centre / right-old)
       prog[k][b-1]   >= min(NS, e + 63)    band above, this sweep   (ghost lane 0)
       prog[k-1][b+1] >= min(NS, e - 60)    band below, previous sweep (ghost lane 63)
-  and at the end of iteration i >= 1 it publishes prog[k][b] = iR (lagging: only stores proven complete), finally NS.
+  and at the end of the segment it publishes prog[k][b] = s_hi - R (lagging: only stores proven complete by the
+  in-order retirement of the memory pipeline), finally NS.
 
 `simulate()` executes exactly that dataflow with numpy (same operation order, no FMA) under a RANDOM task scheduler
 that honours only the progress conditions above, with loads really taken R steps early and publications really
@@ -77,7 +78,7 @@ class Task:
         self.pending_pub = 0
 
 
-def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0):
+def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0, g=2):
     """a1 = omega/(imdx2 + alpha*0.05 + coeff), a2 likewise (see sor_coefficients).  Returns du, dv (H x W)."""
     h, w = phi.shape
     nb, ns, nsp = skew_dims(h, w, r)
@@ -91,6 +92,9 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0):
     lane = np.arange(LANES)
     real = (lane >= 1) & (lane <= 62)
     n_iter = (ns + r - 1) // r
+    assert r % g == 0
+    hseg = r // g
+    n_seg = n_iter * g
     rng = np.random.default_rng(seed)
 
     def covered(b, k, e):
@@ -138,12 +142,13 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0):
                 t.i = 0
                 ran = True
                 break
-            i = t.i
-            if i > 0 and not covered(b, k, (i + 2) * r):
+            i = t.i  # segment index
+            s_lo, s_hi = i * hseg, (i + 1) * hseg
+            if i > 0 and not covered(b, k, s_hi + r):
                 continue
             ran = True
-            for tt in range(r):
-                s = i * r + tt
+            for s in range(s_lo, s_hi):
+                tt = s % r
                 c = t.slots[tt]
                 duU, dvU, phiU = shift_up(t.duL), shift_up(t.dvL), shift_up(t.phiL)
                 duD, dvD = shift_down(c["duR"]), shift_down(c["dvR"])
@@ -167,10 +172,10 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0):
                 t.duL, t.dvL, t.phiL = duN, dvN, c["phi"]
                 t.duC, t.dvC = c["duR"], c["dvR"]
                 t.slots[tt] = load_slot(b, s + r)  # refill R steps ahead: reads memory NOW
-            if i > 0:
-                prog[b, k] = min(ns, i * r)  # lagging publication
+            if s_hi - r > 0:
+                prog[b, k] = min(ns, s_hi - r)  # lagging publication
             t.i += 1
-            if t.i == n_iter:
+            if t.i == n_seg:
                 prog[b, k] = ns
                 pending.pop(ti)
             break
