@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--schedule", default="cfg4", choices=sorted(SCHEDULES))
     ap.add_argument("--mode", default="exact", choices=sorted(MODES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the secondary 4-pairs-in-flight figure")
     ap.add_argument("--pairs", type=int, default=1,
                     help="frame pairs solved concurrently per GPU (one handle + stream + host thread each); a step "
                          "is then one solve of EVERY pair and value counts all of them")
@@ -228,6 +229,32 @@ def main():
                          "avg_launch_ms": round(sor_step * 1e3 / launches, 4) if launches else None,
                          "sor_ms_per_step": round(sor_step * 1e3, 4)},
         }
+        if world == 1 and args.pairs == 1 and not simulate and not args.no_concurrent:
+            # secondary figure (not `value`): the same solve for 4 independent pairs in flight on one GPU -- what a
+            # collection of frame pairs (the reference's TestSuite walks 101 per set) gets out of the device
+            import threading
+            hs = [gpu] + [Papof(local_rank) for _ in range(3)]
+            outs = [(dvx, dvy, dwp)] + [(g2.dev_alloc(h * w * 8), g2.dev_alloc(h * w * 8), g2.dev_alloc(a.nbytes))
+                                        for g2 in hs[1:]]
+
+            def burst():
+                th = [threading.Thread(target=g2.flow_device, args=(d1, d2, h, w, c, args.levels, P) + o)
+                      for g2, o in zip(hs, outs)]
+                for t_ in th:
+                    t_.start()
+                for t_ in th:
+                    t_.join()
+            burst()
+            tb = time.perf_counter()
+            for _ in range(3):
+                burst()
+            tb = (time.perf_counter() - tb) / 3
+            out["concurrent_pairs"] = {"pairs_in_flight": 4, "value": round(4 * h * w / 1e6 / tb, 2), "unit": "Mpix/s",
+                                       "ms_per_burst": round(tb * 1e3, 3)}
+            for g2, o in list(zip(hs, outs))[1:]:
+                for ptr in o:
+                    g2.dev_free(ptr)
+                g2.close()
         if world == 1 and not args.no_cpu_baseline and not simulate:
             kind, dt = cpu_baseline(a, b, args.levels, sched, mode)
             out["cpu_baseline"] = {"value": round(h * w / 1e6 / dt, 5), "unit": "Mpix/s", "cores": 1, "kind": kind,

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py` into profiles/pmc_traffic.json.
+
+Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in KiB; on gfx950
+FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE reads
+exactly for 16-byte-per-lane streaming stores.  Infinity-Cache hits are counted too (these are L2 fabric-side
+requests), so "traffic" is an upper bound of the HBM bytes.
+
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <key> [kernel substring]
+"""
+import csv
+import json
+import os
+import sys
+
+
+def per_dispatch(path, counter, kernel):
+    vals = []
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") == counter and kernel in r.get("Kernel_Name", ""):
+            vals.append(float(r["Counter_Value"]))
+    return vals
+
+
+def main():
+    fetch_csv, write_csv, key = sys.argv[1:4]
+    kernel = sys.argv[4] if len(sys.argv) > 4 else "k_sor_exact"
+    f = per_dispatch(fetch_csv, "FETCH_SIZE", kernel)
+    w = per_dispatch(write_csv, "WRITE_SIZE", kernel)
+    out = {"kernel": kernel, "launches_sampled": [len(f), len(w)],
+           "fetch_kib_raw_avg": sum(f) / len(f), "write_kib_avg": sum(w) / len(w),
+           "bytes_per_launch": int((2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024),
+           "note": "FETCH_SIZE doubled (gfx950 half-count of wide coalesced reads); includes Infinity-Cache hits"}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "profiles", "pmc_traffic.json")
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data[key] = out["bytes_per_launch"]
+    data[key + "_detail"] = out
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
