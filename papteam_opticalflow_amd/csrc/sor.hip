@@ -336,9 +336,14 @@ struct Segments {
                                                bool lane0) {
         constexpr int H = R / G;
         const int s_lo = i * R + g * H, s_hi = s_lo + H;
-        // loads issued by steps [s_lo, s_hi) are those of steps [s_lo + R, s_hi + R)
-        if ((i > 0 || g > 0) && !wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, s_hi + R)) return false;
-        const Polls pn = poll(p_own, p_up, p_dn, prev, has_up, has_dn);  // poll for the next segment
+        // Coverage is checked once per iteration, for all the loads it will issue (those of steps < (i + 2) R):
+        // consuming a poll forces an in-order vmcnt wait on every older load, so finer-grained polling stalls the
+        // pipeline (measured).  Publication below has no such cost and is done every segment.
+        Polls pn = pl;
+        if (g == 0) {
+            if (i > 0 && !wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, (i + 2) * R)) return false;
+            pn = poll(p_own, p_up, p_dn, prev, has_up, has_dn);  // poll for the next iteration
+        }
         Seg<R, g * H, (g + 1) * H, DPP>::run(A, T, L, om1, i * R, c, S);
         pl = pn;
         // Lagged publication without draining the memory pipeline: vmcnt retires in issue order and the slot consumed
