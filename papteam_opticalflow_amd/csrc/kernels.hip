@@ -273,15 +273,14 @@ __device__ __forceinline__ void sor_diagonals(const double* __restrict__ phi, in
 //   a1, a2     = hoisted SOR diagonals (above)
 // Reads 2*planes + 3 streams, writes 6 SOR operand planes in the layout the solver wants.
 // ------------------------------------------------------------------------------------------------
-template <bool SKEW>
-__global__ void k_assemble(const double* __restrict__ blend, const double* __restrict__ imdt,
-                           const double* __restrict__ phi, const double* __restrict__ u,
-                           const double* __restrict__ v, int H, int W, int planes, double alpha, double omega,
-                           int ns, double* __restrict__ o_phi, double* __restrict__ o_xy, double* __restrict__ o_a1,
-                           double* __restrict__ o_a2, double* __restrict__ o_b1, double* __restrict__ o_b2,
-                           double* __restrict__ o_x2, double* __restrict__ o_y2, Taps d) {
-    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
-    if (j >= W || i >= H) return;
+struct SystemCell {
+    double phi, xy, a1, a2, b1, b2, x2, y2;
+};
+
+__device__ __forceinline__ SystemCell assemble_cell(const double* __restrict__ blend, const double* __restrict__ imdt,
+                                                    const double* __restrict__ phi, const double* __restrict__ u,
+                                                    const double* __restrict__ v, int i, int j, int H, int W,
+                                                    int planes, double alpha, double omega, const Taps& d) {
     const size_t np = (size_t)H * W, o = (size_t)i * W + j;
     double sxy = 0.0, sx2 = 0.0, sy2 = 0.0, stx = 0.0, sty = 0.0;
     for (int k = 0; k < planes; k++) {
@@ -317,19 +316,85 @@ __global__ void k_assemble(const double* __restrict__ blend, const double* __res
         stx = stx / planes;
         sty = sty / planes;
     }
-    const double b1 = -stx - alpha * laplacian_at(u, phi, i, j, H, W);
-    const double b2 = -sty - alpha * laplacian_at(v, phi, i, j, H, W);
-    double a1, a2;
-    sor_diagonals(phi, i, j, H, W, sx2, sy2, alpha, omega, a1, a2);
-    const size_t q = sor_index<SKEW>(i, j, W, ns);
-    o_phi[q] = phi[o];
-    o_xy[q] = sxy;
-    o_a1[q] = a1;
-    o_a2[q] = a2;
-    o_b1[q] = b1;
-    o_b2[q] = b2;
-    if (o_x2) o_x2[o] = sx2;
-    if (o_y2) o_y2[o] = sy2;
+    SystemCell c;
+    c.b1 = -stx - alpha * laplacian_at(u, phi, i, j, H, W);
+    c.b2 = -sty - alpha * laplacian_at(v, phi, i, j, H, W);
+    sor_diagonals(phi, i, j, H, W, sx2, sy2, alpha, omega, c.a1, c.a2);
+    c.phi = phi[o];
+    c.xy = sxy;
+    c.x2 = sx2;
+    c.y2 = sy2;
+    return c;
+}
+
+// row-major operands (red-black / Jacobi modes): one thread per cell
+__global__ void k_assemble(const double* __restrict__ blend, const double* __restrict__ imdt,
+                           const double* __restrict__ phi, const double* __restrict__ u,
+                           const double* __restrict__ v, int H, int W, int planes, double alpha, double omega,
+                           double* __restrict__ o_phi, double* __restrict__ o_xy, double* __restrict__ o_a1,
+                           double* __restrict__ o_a2, double* __restrict__ o_b1, double* __restrict__ o_b2,
+                           double* __restrict__ o_x2, double* __restrict__ o_y2, Taps d) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t o = (size_t)i * W + j;
+    const SystemCell c = assemble_cell(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d);
+    o_phi[o] = c.phi;
+    o_xy[o] = c.xy;
+    o_a1[o] = c.a1;
+    o_a2[o] = c.a2;
+    o_b1[o] = c.b1;
+    o_b2[o] = c.b2;
+    if (o_x2) o_x2[o] = c.x2;
+    if (o_y2) o_y2[o] = c.y2;
+}
+
+// Skewed, paired operands of the exact-order solver.  A block owns one band (62 rows) x kTileJ columns:
+// cells are COMPUTED in row-major order (coalesced plane reads), staged in LDS, and WRITTEN in skew order --
+// for one skew position the 16 threads of a group store 16 neighbouring lanes = 256 contiguous bytes per paired
+// plane -- instead of one 16-byte cell per kilobyte.
+constexpr int kTileJ = 16;
+struct double2s {
+    double x, y;
+};
+__global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict__ blend,
+                                                       const double* __restrict__ imdt,
+                                                       const double* __restrict__ phi, const double* __restrict__ u,
+                                                       const double* __restrict__ v, int H, int W, int planes,
+                                                       double alpha, double omega, int nsp,
+                                                       double2s* __restrict__ pa, double2s* __restrict__ pb,
+                                                       double2s* __restrict__ pc, double* __restrict__ o_x2,
+                                                       double* __restrict__ o_y2, Taps d) {
+    __shared__ double stage[6][kBandRows][kTileJ + 1];
+    const int b = blockIdx.y, j0 = blockIdx.x * kTileJ, tid = threadIdx.x;
+    for (int c = tid; c < kBandRows * kTileJ; c += 256) {
+        const int r = c / kTileJ, jj = c - r * kTileJ;
+        const int i = b * kBandRows + r, j = j0 + jj;
+        if (i < H && j < W) {
+            const SystemCell s = assemble_cell(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d);
+            stage[0][r][jj] = s.phi;
+            stage[1][r][jj] = s.xy;
+            stage[2][r][jj] = s.a1;
+            stage[3][r][jj] = s.a2;
+            stage[4][r][jj] = s.b1;
+            stage[5][r][jj] = s.b2;
+            if (o_x2) o_x2[(size_t)i * W + j] = s.x2;
+            if (o_y2) o_y2[(size_t)i * W + j] = s.y2;
+        }
+    }
+    __syncthreads();
+    const int g = tid / kTileJ, jj = tid - g * kTileJ;  // 16 groups of 16 threads; a group walks skew positions
+    const int j = j0 + jj;
+    if (j >= W) return;
+    for (int pp = 1 + g; pp <= kBandRows + kTileJ - 1; pp += 256 / kTileJ) {  // pp = jj + lane
+        const int l = pp - jj;
+        if (l < 1 || l > kBandRows) continue;
+        const int r = l - 1, i = b * kBandRows + r;
+        if (i >= H) continue;
+        const size_t q = ((size_t)b * nsp + (size_t)(j + l)) * kLanes + l;
+        pa[q] = double2s{stage[0][r][jj], stage[1][r][jj]};
+        pb[q] = double2s{stage[2][r][jj], stage[3][r][jj]};
+        pc[q] = double2s{stage[4][r][jj], stage[5][r][jj]};
+    }
 }
 
 // stage helper: SOR operands from already assembled row-major planes (tests / micro-benchmark)
@@ -368,17 +433,32 @@ __global__ void k_sor_unpack(const double* __restrict__ sdu, const double* __res
 // Phase 6, src/OpticalFlow.cpp:513-516: u += du, v += dv (Image::Add, src/Image.h:1925-1941) and re-warp
 // frame 2 with the updated flow -- fused, the update of a pixel only feeds its own warp.
 // ------------------------------------------------------------------------------------------------
-template <bool SKEW>
 __global__ void k_update_warp(const double* __restrict__ sdu, const double* __restrict__ sdv, double* __restrict__ u,
                               double* __restrict__ v, const double* __restrict__ im1,
-                              const double* __restrict__ im2, double* __restrict__ warp, int H, int W, int planes,
-                              int ns) {
+                              const double* __restrict__ im2, double* __restrict__ warp, int H, int W, int planes) {
     const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
     if (j >= W || i >= H) return;
-    const size_t q = sor_index<SKEW>(i, j, W, ns), o = (size_t)i * W + j;
+    const size_t o = (size_t)i * W + j;
     double fu = u[o], fv = v[o];
-    fu += sdu[q];
-    fv += sdv[q];
+    fu += sdu[o];
+    fv += sdv[o];
+    u[o] = fu;
+    v[o] = fv;
+    warp_pixel(im1, im2, warp, fu, fv, i, j, H, W, planes);
+}
+
+// Exact-order solver layout: (du, dv) read straight from the paired skewed plane (16 bytes per thread; an LDS-staged
+// transposition of the tile was measured slower: the kernel is bound by the 4-tap x C-plane gather of the warp).
+__global__ void k_update_warp_skew(const double2s* __restrict__ pd, double* __restrict__ u, double* __restrict__ v,
+                                   const double* __restrict__ im1, const double* __restrict__ im2,
+                                   double* __restrict__ warp, int H, int W, int planes, int nsp) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t o = (size_t)i * W + j;
+    const double2s c = pd[sor_index<true>(i, j, W, nsp) / 2];
+    double fu = u[o], fv = v[o];
+    fu += c.x;
+    fv += c.y;
     u[o] = fu;
     v[o] = fv;
     warp_pixel(im1, im2, warp, fu, fv, i, j, H, W, planes);
@@ -571,15 +651,16 @@ int compute_phi(papof_handle* h, const double* u, const double* v, double* phi, 
 int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,
                     const double* v, int H, int W, int planes, double alpha, double omega, const SorPlanes& out,
                     double* opt_imdx2, double* opt_imdy2) {
-    const int ns = skew_dims(H, W).nsp;
-    if (out.skew)
-        hipLaunchKernelGGL(k_assemble<true>, grid2d(W, H), dim3(BX, BY), 0, h->stream, blend, imdt, phi, u, v, H, W,
-                           planes, alpha, omega, ns, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2, opt_imdx2,
-                           opt_imdy2, deriv5_taps());
-    else
-        hipLaunchKernelGGL(k_assemble<false>, grid2d(W, H), dim3(BX, BY), 0, h->stream, blend, imdt, phi, u, v, H,
-                           W, planes, alpha, omega, ns, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2, opt_imdx2,
-                           opt_imdy2, deriv5_taps());
+    if (out.skew) {
+        const SkewDims sd = skew_dims(H, W);
+        hipLaunchKernelGGL(k_assemble_skew, dim3((W + kTileJ - 1) / kTileJ, sd.nb), dim3(256), 0, h->stream, blend,
+                           imdt, phi, u, v, H, W, planes, alpha, omega, sd.nsp, (double2s*)out.phi, (double2s*)out.a1,
+                           (double2s*)out.b1, opt_imdx2, opt_imdy2, deriv5_taps());
+    } else {
+        hipLaunchKernelGGL(k_assemble, grid2d(W, H), dim3(BX, BY), 0, h->stream, blend, imdt, phi, u, v, H, W, planes,
+                           alpha, omega, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2, opt_imdx2, opt_imdy2,
+                           deriv5_taps());
+    }
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
@@ -592,13 +673,14 @@ int laplacian(papof_handle* h, const double* in, const double* weight, double* o
 
 int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, const double* im1,
                     const double* im2, double* warp, int H, int W, int planes) {
-    const int ns = skew_dims(H, W).nsp;
-    if (sp.skew)
-        hipLaunchKernelGGL(k_update_warp<true>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, u, v, im1,
-                           im2, warp, H, W, planes, ns);
-    else
-        hipLaunchKernelGGL(k_update_warp<false>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, u, v, im1,
-                           im2, warp, H, W, planes, ns);
+    if (sp.skew) {
+        const SkewDims sd = skew_dims(H, W);
+        hipLaunchKernelGGL(k_update_warp_skew, grid2d(W, H), dim3(BX, BY), 0, h->stream, (const double2s*)sp.du, u, v,
+                           im1, im2, warp, H, W, planes, sd.nsp);
+    } else {
+        hipLaunchKernelGGL(k_update_warp, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, u, v, im1, im2, warp,
+                           H, W, planes);
+    }
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
