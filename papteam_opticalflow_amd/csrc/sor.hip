@@ -429,10 +429,41 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     }
     Unroll<R, R - 1, DPP>::fill(T, L, c);
 
-    for (int i = 0; i < n_iter; ++i)
-        if (!Segments<R, G, 0, DPP>::run(A, T, L, om1, i, c, S, pl, my_prog, p_own, p_up, p_dn, prev, has_up, has_dn,
-                                         lane == 0))
-            return;
+    if constexpr (G == 1 && R >= 8) {
+        // MARKER loads: a 4-byte load issued right after the store of some step retires (vmcnt is in order) only
+        // after that store has completed, so consuming it a few steps later proves the step complete and lets the
+        // task publish it without draining the pipeline.  Two markers per iteration (after steps H-1 and R-1),
+        // each consumed D = 3 steps later: published progress lags the real one by 3..7 steps instead of R..2R.
+        constexpr int H = R / 2, D = 3;
+        static_assert(H > D, "marker distance must fit in half an iteration");
+        unsigned mb = 0u;
+        for (int i = 0; i < n_iter; ++i) {
+            if (i > 0 && !wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, (i + 2) * R)) return;
+            const Polls pn = poll(p_own, p_up, p_dn, prev, has_up, has_dn);
+            Seg<R, 0, D, DPP>::run(A, T, L, om1, i * R, c, S);
+            if (i > 0) {  // marker issued after step i*R - 1
+                asm volatile("" ::"v"(mb), "v"(S.duL), "v"(S.dvL) : "memory");
+                if (mb != 0u) return;  // another task raised the abort word
+                if (lane == 0)
+                    __hip_atomic_store(my_prog, (unsigned)min(ns, i * R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            Seg<R, D, H, DPP>::run(A, T, L, om1, i * R, c, S);
+            const unsigned ma = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            Seg<R, H, H + D, DPP>::run(A, T, L, om1, i * R, c, S);
+            asm volatile("" ::"v"(ma), "v"(S.duL), "v"(S.dvL) : "memory");
+            if (ma != 0u) return;
+            if (lane == 0)
+                __hip_atomic_store(my_prog, (unsigned)min(ns, i * R + H), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            Seg<R, H + D, R, DPP>::run(A, T, L, om1, i * R, c, S);
+            mb = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pl = pn;
+        }
+    } else {
+        for (int i = 0; i < n_iter; ++i)
+            if (!Segments<R, G, 0, DPP>::run(A, T, L, om1, i, c, S, pl, my_prog, p_own, p_up, p_dn, prev, has_up,
+                                             has_dn, lane == 0))
+                return;
+    }
     // final publication: every store of this wave has left the CU before the counter moves (guide G16/R1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(my_prog, (unsigned)ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -16,8 +16,9 @@ thousands of cells concurrently.  Work decomposition, as in the H
       prog[k-1][b]   >= min(NS, e + 1)     own band, previous sweep (centre / right-old)
       prog[k][b-1]   >= min(NS, e + 63)    band above, this sweep   (ghost lane 0)
       prog[k-1][b+1] >= min(NS, e - 60)    band below, previous sweep (ghost lane 63)
-  and at the end of the segment it publishes prog[k][b] = s_hi - R (lagging: only stores proven complete by the
-  in-order retirement of the memory pipeline), finally NS.
+  and it publishes only steps whose stores are PROVEN complete by the in-order retirement of the memory pipeline:
+  with G = 1 and R >= 8 (the shipped configuration) two marker loads per iteration let it publish i*R + R/2 by the
+  end of iteration i; otherwise s_hi - R at the end of a segment; finally NS after a full drain.
 
 `simulate()` executes exactly that dataflow with numpy (same operation order, no FMA) under a RANDOM task scheduler
 that honours only the progress conditions above, with loads really taken R steps early and publications really
@@ -172,7 +173,10 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0, g=2):
                 t.duL, t.dvL, t.phiL = duN, dvN, c["phi"]
                 t.duC, t.dvC = c["duR"], c["dvR"]
                 t.slots[tt] = load_slot(b, s + r)  # refill R steps ahead: reads memory NOW
-            if s_hi - r > 0:
+            if g == 1 and r >= 8:
+                # marker scheme of the kernel: by the end of iteration i it has published i*R + R/2
+                prog[b, k] = min(ns, i * r + r // 2)
+            elif s_hi - r > 0:
                 prog[b, k] = min(ns, s_hi - r)  # lagging publication
             t.i += 1
             if t.i == n_seg:
