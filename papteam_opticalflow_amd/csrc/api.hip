@@ -35,10 +35,10 @@ double wall() {
 }
 
 // generous upper bound of the arena one call needs: every buffer is at most level-0 sized
-size_t arena_bytes_for(int H, int W, int C, int levels) {
+size_t arena_bytes_for(int H, int W, int C, int levels, int n_sor_max) {
     const size_t np = (size_t)H * W;
     const int fc = (C == 3) ? 5 : (C == 1 ? 3 : C);
-    const SkewDims sd = skew_dims(H, W);
+    const SkewDims sd = skew_dims(H, W, n_sor_max);
     size_t planes = 0;
     planes += (size_t)2 * C * 5;           // two pyramids: sum of ratio^(2i) < 2.3 for ratio<=.75; 5 is safe to .98
     if (levels > 8) planes += (size_t)2 * C * levels;  // (ratio .98 decays slowly: bound by level count)
@@ -47,7 +47,7 @@ size_t arena_bytes_for(int H, int W, int C, int levels) {
     planes += 8;                           // u, v, resized u, v, phi + slack
     planes += (size_t)3 * C + C;           // bicubic derivative planes + interleaved output
     size_t bytes = planes * np * sizeof(double);
-    bytes += 10 * sd.n * sizeof(double);   // SOR operands (skewed is the larger layout)
+    bytes += 4 * (sd.n + 2 * kLanes) * 16 + 10 * np * sizeof(double);  // SOR operands: paired skewed planes / row-major
     bytes += (size_t)64 * 4096;            // alignment slack
     return bytes;
 }
@@ -180,14 +180,14 @@ struct SolveBuffers {
     SorPlanes sp;
 };
 
-int alloc_solve_buffers(Arena& A, int H, int W, int fc, int mode, SolveBuffers& B) {
+int alloc_solve_buffers(Arena& A, int H, int W, int fc, int mode, int n_sor_cap, SolveBuffers& B) {
     const size_t np = (size_t)H * W;
     B.im1s = A.f64(np * fc);
     B.tmp = A.f64(np * fc);
     B.blend = A.f64(np * fc);
     B.imdt = A.f64(np * fc);
     B.phi = A.f64(np);
-    PAPOF_TRY(sor_alloc_planes(A, H, W, mode, B.sp));
+    PAPOF_TRY(sor_alloc_planes(A, H, W, mode, n_sor_cap, B.sp));
     return A.overflow ? PAPOF_ENOMEM : PAPOF_OK;
 }
 
@@ -233,7 +233,8 @@ int flow_device(papof_handle* h, const double* d_im1, const double* d_im2, int H
     std::vector<Level> L;
     std::vector<PyrPlan> plan;
     PAPOF_TRY(pyramid_plan(H, W, P.ratio, levels, L, plan));
-    PAPOF_TRY(ensure_arena(h, arena_bytes_for(H, W, C, levels)));
+    const int n_sor_max = P.n_sor + (levels - 1) * P.n_sor_per_level;
+    PAPOF_TRY(ensure_arena(h, arena_bytes_for(H, W, C, levels, n_sor_max)));
     Arena& A = h->arena;
     A.off = 0;
     A.overflow = false;
@@ -268,7 +269,7 @@ int flow_device(papof_handle* h, const double* d_im1, const double* d_im2, int H
     double* u2 = A.f64(np0);
     double* v2 = A.f64(np0);
     SolveBuffers B;
-    PAPOF_TRY(alloc_solve_buffers(A, H, W, fc, P.sor_mode, B));
+    PAPOF_TRY(alloc_solve_buffers(A, H, W, fc, P.sor_mode, n_sor_max, B));
     if (A.overflow) return PAPOF_ENOMEM;
 
     int pw = 0, ph = 0;
@@ -290,7 +291,8 @@ int flow_device(papof_handle* h, const double* d_im1, const double* d_im2, int H
             std::swap(v, v2);
             PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc));
         }
-        PAPOF_TRY(sor_reset_planes(h, B.sp, lh, lw));
+        PAPOF_TRY(sor_bind(B.sp, lh, lw, P.n_sor + k * P.n_sor_per_level));
+        PAPOF_TRY(sor_reset_planes(h, B.sp));
         PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, lh, lw, fc, P.alpha, P.n_outer + k * P.n_outer_per_level,
                               P.n_sor + k * P.n_sor_per_level, P.omega, P.sor_mode, B, clk, sorclk));
         pw = lw;
@@ -783,8 +785,9 @@ int papof_stage_laplacian(papof_handle* h, const double* in, const double* weigh
 }
 
 namespace {
-int alloc_sor_planes(Scope& S, int H, int W, int mode, SorPlanes& sp) {
-    int rc = sor_alloc_planes(S.h->arena, H, W, mode, sp);
+int alloc_sor_planes(Scope& S, int H, int W, int mode, int n_sor, SorPlanes& sp) {
+    int rc = sor_alloc_planes(S.h->arena, H, W, mode, n_sor, sp);
+    if (rc == PAPOF_OK) rc = sor_bind(sp, H, W, n_sor);
     if (rc != PAPOF_OK) S.rc = rc;
     return S.rc;
 }
@@ -797,7 +800,7 @@ int papof_stage_sor(papof_handle* h, const double* phi, const double* imdxy, con
         n_sor < 1 || sor_mode < PAPOF_SOR_EXACT || sor_mode > PAPOF_SOR_JACOBI)
         return PAPOF_EINVAL;
     const size_t np = (size_t)height * width;
-    Scope S(h, img_bytes(height, width, 1, 16) + 12 * (skew_dims(height, width).n + 64) * sizeof(double));
+    Scope S(h, img_bytes(height, width, 1, 16) + 5 * (skew_dims(height, width, n_sor).n + 128) * 16 + 12 * (size_t)height * width * sizeof(double));
     PAPOF_TRY(S.rc);
     double* p = S.up_planar(phi, height, width, 1);
     double* xy = S.up_planar(imdxy, height, width, 1);
@@ -807,8 +810,8 @@ int papof_stage_sor(papof_handle* h, const double* phi, const double* imdxy, con
     double* r2 = S.up_planar(rhs2, height, width, 1);
     double *ou = S.dev(np), *ov = S.dev(np);
     SorPlanes sp{};
-    PAPOF_TRY(alloc_sor_planes(S, height, width, sor_mode, sp));
-    PAPOF_TRY(sor_reset_planes(h, sp, height, width));
+    PAPOF_TRY(alloc_sor_planes(S, height, width, sor_mode, n_sor, sp));
+    PAPOF_TRY(sor_reset_planes(h, sp));
     PAPOF_TRY(sor_prep(h, p, xy, x2, y2, r1, r2, height, width, alpha, omega, sp));
     PAPOF_TRY(sor_solve(h, sp, height, width, alpha, omega, n_sor, sor_mode));
     PAPOF_TRY(sor_unpack(h, sp, ou, ov, height, width));
@@ -826,7 +829,7 @@ int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2
         return PAPOF_EINVAL;
     if (n_inner != 1) return PAPOF_EINVAL;
     Scope S(h, img_bytes(height, width, c, 12) + img_bytes(height, width, 1, 8) +
-                   12 * (skew_dims(height, width).n + 64) * sizeof(double));
+                   5 * (skew_dims(height, width, n_sor).n + 128) * 16 + 12 * (size_t)height * width * sizeof(double));
     PAPOF_TRY(S.rc);
     double* f1 = S.up_planar(im1, height, width, c);
     double* f2 = S.up_planar(im2, height, width, c);
@@ -835,8 +838,9 @@ int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2
     double* dv = S.up_planar(v, height, width, 1);
     PAPOF_TRY(S.rc);
     SolveBuffers B;
-    PAPOF_TRY(alloc_solve_buffers(h->arena, height, width, c, sor_mode, B));
-    PAPOF_TRY(sor_reset_planes(h, B.sp, height, width));
+    PAPOF_TRY(alloc_solve_buffers(h->arena, height, width, c, sor_mode, n_sor, B));
+    PAPOF_TRY(sor_bind(B.sp, height, width, n_sor));
+    PAPOF_TRY(sor_reset_planes(h, B.sp));
     PhaseClock clk{h, false}, sorclk{h, false};
     PAPOF_TRY(smooth_flow(h, f1, f2, w, du, dv, height, width, c, alpha, n_outer, n_sor, omega, sor_mode, B, clk,
                           sorclk));
@@ -877,7 +881,7 @@ int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_m
         sor_mode > PAPOF_SOR_JACOBI)
         return PAPOF_EINVAL;
     const size_t np = (size_t)height * width;
-    Scope S(h, img_bytes(height, width, 1, 16) + 12 * (skew_dims(height, width).n + 64) * sizeof(double));
+    Scope S(h, img_bytes(height, width, 1, 16) + 5 * (skew_dims(height, width, n_sor).n + 128) * 16 + 12 * (size_t)height * width * sizeof(double));
     PAPOF_TRY(S.rc);
     std::vector<double> host(np * 6);
     std::mt19937_64 rng(seed);
@@ -894,8 +898,8 @@ int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_m
     double* planes[6];
     for (int k = 0; k < 6; k++) planes[k] = S.up_planar(host.data() + k * np, height, width, 1);
     SorPlanes sp{};
-    PAPOF_TRY(alloc_sor_planes(S, height, width, sor_mode, sp));
-    PAPOF_TRY(sor_reset_planes(h, sp, height, width));
+    PAPOF_TRY(alloc_sor_planes(S, height, width, sor_mode, n_sor, sp));
+    PAPOF_TRY(sor_reset_planes(h, sp));
     PAPOF_TRY(sor_prep(h, planes[0], planes[1], planes[2], planes[3], planes[4], planes[5], height, width, 0.012, 1.8,
                        sp));
     PAPOF_TRY(sor_solve(h, sp, height, width, 0.012, 1.8, n_sor, sor_mode));  // warm-up

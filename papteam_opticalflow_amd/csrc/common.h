@@ -71,22 +71,30 @@ struct Arena {
 };
 
 constexpr int kSorMaxDepth = 32;  // largest software-pipeline depth (steps) of the exact-order SOR kernel
+constexpr int kBandRows = kLanes - 2;  // real rows per task: lanes 1..62; lanes 0 / 63 stand for the rows above / below
 
-constexpr int kBandRows = kLanes - 2;  // real rows per band: lanes 1..62; lanes 0 / 63 mirror the rows above / below
-
+// Layout of the exact-order solver's operand planes ("globally skewed", paired 16-byte cells):
+//   cell (row i, column j)  ->  index (i + j + qt) * hp + (i + rt)
+// i.e. one POSITION per anti-diagonal, the rows of a position contiguous.  A task (band b, sweep k) owns the rows
+// 62b - k .. 62b - k + 61 (bands climb one row per sweep, see sor.hip), so at step s its 64 lanes touch the 64
+// consecutive cells (position 62b - k - 1 + qt + s, rows 62b - k - 1 + rt ...) -- one contiguous 1-KiB access.
+// Every cell that is not a real (row, column) of the image holds 0.0.
 struct SkewDims {
-    int nb;     // bands of kBandRows rows
-    int ns;     // steps per task that touch real cells = W + 63
-    int nsp;    // band stride in skew positions: ns rounded up plus two pipeline depths of spare positions, so the
-                // kernel may run / prefetch whole iterations past ns without leaving its own band
-    size_t n;   // doubles per skewed plane (all positions that are not real cells must hold 0.0)
+    int nb;      // bands = tasks per sweep
+    int ns;      // steps per task = W + 63
+    int rt, qt;  // padding rows above row 0 / positions before position 0 (n_sor + 1: room for the climbing bands)
+    int hp;      // storage rows per position (multiple of 8 => 128-byte aligned positions)
+    int npos;    // positions
+    size_t n;    // cells per paired plane
 };
-inline SkewDims skew_dims(int h, int w) {
+inline SkewDims skew_dims(int h, int w, int n_sor) {
     SkewDims d;
-    d.nb = (h + kBandRows - 1) / kBandRows;
+    d.nb = (h + n_sor - 1 + kBandRows - 1) / kBandRows;
     d.ns = w + kLanes - 1;
-    d.nsp = (d.ns + kSorMaxDepth - 1) / kSorMaxDepth * kSorMaxDepth + 2 * kSorMaxDepth;
-    d.n = (size_t)d.nb * d.nsp * kLanes;
+    d.rt = d.qt = n_sor + 1;
+    d.hp = (d.rt + kBandRows * d.nb + 2 + 7) / 8 * 8;
+    d.npos = d.qt + d.ns + 2 * kSorMaxDepth + 2 + kBandRows * (d.nb - 1) + 2;
+    d.n = (size_t)d.npos * d.hp;
     return d;
 }
 
@@ -100,6 +108,8 @@ struct SorPlanes {
     double *du, *dv;                       // unknowns (written from zero; no initialisation needed)
     double *du2, *dv2;                     // Jacobi ping-pong (row-major modes only)
     bool skew;
+    SkewDims sd;                           // skew mode: layout bound by sor_bind() for (H, W, n_sor) of this solve
+    size_t cap_cells;                      // skew mode: cells each paired plane can hold
 };
 
 }  // namespace papof
@@ -153,8 +163,9 @@ Taps central3_taps();
 // ---- sor.hip ----
 int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor, int mode);
 int sor_check(papof_handle* h);  // after a stream sync: PAPOF_ETIMEOUT if a device-side wait expired
-int sor_reset_planes(papof_handle* h, const SorPlanes& sp, int H, int W);  // zero the padding (once per level)
-int sor_alloc_planes(Arena& A, int H, int W, int mode, SorPlanes& sp);      // carve the operands of one solve
+int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes& sp);  // carve the operand planes
+int sor_bind(SorPlanes& sp, int H, int W, int n_sor);          // choose the layout of the next solves (skew mode)
+int sor_reset_planes(papof_handle* h, const SorPlanes& sp);    // zero all padding of the bound layout
 int sor_probe_dpp(papof_handle* h);  // sets h->use_dpp after checking the cross-lane DPP semantics on the device
 
 }  // namespace papof

@@ -211,13 +211,17 @@ __global__ void k_phi(const double* __restrict__ u, const double* __restrict__ v
     phi[o] = 0.5 / sqrt(t + 0.001 * 0.001);
 }
 
-// index of cell (i, j) in an SOR operand plane
+// index (in doubles) of cell (i, j) in an SOR operand plane.  Skew mode: paired planes, (phi,xy) (a1,a2) (b1,b2)
+// (du,dv) interleaved, cell (i, j) at (i + j + qt) * hp + (i + rt) -- see common.h.
+struct SkewIdx {
+    int hp, qt, rt;
+};
+__device__ __forceinline__ size_t skew_cell(int i, int j, const SkewIdx& k) {
+    return (size_t)(i + j + k.qt) * k.hp + (size_t)(i + k.rt);
+}
 template <bool SKEW>
-__device__ __forceinline__ size_t sor_index(int i, int j, int W, int nsp) {
-    if (SKEW) {  // paired planes: (phi,xy) (a1,a2) (b1,b2) (du,dv) are interleaved, see common.h
-        const int b = i / kBandRows, l = 1 + (i - b * kBandRows);  // lanes 1..62 carry real rows
-        return 2 * (((size_t)b * nsp + (j + l)) * kLanes + l);
-    }
+__device__ __forceinline__ size_t sor_index(int i, int j, int W, const SkewIdx& k) {
+    if (SKEW) return 2 * skew_cell(i, j, k);
     return (size_t)i * W + j;
 }
 
@@ -348,10 +352,10 @@ __global__ void k_assemble(const double* __restrict__ blend, const double* __res
     if (o_y2) o_y2[o] = c.y2;
 }
 
-// Skewed, paired operands of the exact-order solver.  A block owns one band (62 rows) x kTileJ columns:
-// cells are COMPUTED in row-major order (coalesced plane reads), staged in LDS, and WRITTEN in skew order --
-// for one skew position the 16 threads of a group store 16 neighbouring lanes = 256 contiguous bytes per paired
-// plane -- instead of one 16-byte cell per kilobyte.
+// Skewed, paired operands of the exact-order solver.  A block owns a tile of 62 rows x kTileJ columns: cells are
+// COMPUTED in row-major order (coalesced plane reads), staged in LDS, and WRITTEN in skew order -- for one skew
+// position (anti-diagonal) the 16 threads of a group store 16 neighbouring rows = 256 contiguous bytes per paired
+// plane -- instead of scattered 16-byte cells.
 constexpr int kTileJ = 16;
 struct double2s {
     double x, y;
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
                                                        const double* __restrict__ imdt,
                                                        const double* __restrict__ phi, const double* __restrict__ u,
                                                        const double* __restrict__ v, int H, int W, int planes,
-                                                       double alpha, double omega, int nsp,
+                                                       double alpha, double omega, SkewIdx sk,
                                                        double2s* __restrict__ pa, double2s* __restrict__ pb,
                                                        double2s* __restrict__ pc, double* __restrict__ o_x2,
                                                        double* __restrict__ o_y2, Taps d) {
@@ -382,15 +386,15 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
         }
     }
     __syncthreads();
-    const int g = tid / kTileJ, jj = tid - g * kTileJ;  // 16 groups of 16 threads; a group walks skew positions
+    const int g = tid / kTileJ, jj = tid - g * kTileJ;  // 16 groups of 16 threads; a group walks anti-diagonals
     const int j = j0 + jj;
     if (j >= W) return;
-    for (int pp = 1 + g; pp <= kBandRows + kTileJ - 1; pp += 256 / kTileJ) {  // pp = jj + lane
-        const int l = pp - jj;
-        if (l < 1 || l > kBandRows) continue;
-        const int r = l - 1, i = b * kBandRows + r;
+    for (int pp = g; pp <= kBandRows + kTileJ - 2; pp += 256 / kTileJ) {  // pp = jj + (row in tile)
+        const int r = pp - jj;
+        if (r < 0 || r >= kBandRows) continue;
+        const int i = b * kBandRows + r;
         if (i >= H) continue;
-        const size_t q = ((size_t)b * nsp + (size_t)(j + l)) * kLanes + l;
+        const size_t q = skew_cell(i, j, sk);
         pa[q] = double2s{stage[0][r][jj], stage[1][r][jj]};
         pb[q] = double2s{stage[2][r][jj], stage[3][r][jj]};
         pc[q] = double2s{stage[4][r][jj], stage[5][r][jj]};
@@ -402,7 +406,7 @@ template <bool SKEW>
 __global__ void k_sor_prep(const double* __restrict__ phi, const double* __restrict__ imdxy,
                            const double* __restrict__ imdx2, const double* __restrict__ imdy2,
                            const double* __restrict__ rhs1, const double* __restrict__ rhs2, int H, int W,
-                           double alpha, double omega, int ns, double* __restrict__ o_phi,
+                           double alpha, double omega, SkewIdx sk, double* __restrict__ o_phi,
                            double* __restrict__ o_xy, double* __restrict__ o_a1, double* __restrict__ o_a2,
                            double* __restrict__ o_b1, double* __restrict__ o_b2) {
     const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
@@ -410,7 +414,7 @@ __global__ void k_sor_prep(const double* __restrict__ phi, const double* __restr
     const size_t o = (size_t)i * W + j;
     double a1, a2;
     sor_diagonals(phi, i, j, H, W, imdx2[o], imdy2[o], alpha, omega, a1, a2);
-    const size_t q = sor_index<SKEW>(i, j, W, ns);
+    const size_t q = sor_index<SKEW>(i, j, W, sk);
     o_phi[q] = phi[o];
     o_xy[q] = imdxy[o];
     o_a1[q] = a1;
@@ -421,10 +425,10 @@ __global__ void k_sor_prep(const double* __restrict__ phi, const double* __restr
 
 template <bool SKEW>
 __global__ void k_sor_unpack(const double* __restrict__ sdu, const double* __restrict__ sdv,
-                             double* __restrict__ du, double* __restrict__ dv, int H, int W, int ns) {
+                             double* __restrict__ du, double* __restrict__ dv, int H, int W, SkewIdx sk) {
     const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
     if (j >= W || i >= H) return;
-    const size_t q = sor_index<SKEW>(i, j, W, ns), o = (size_t)i * W + j;
+    const size_t q = sor_index<SKEW>(i, j, W, sk), o = (size_t)i * W + j;
     du[o] = sdu[q];
     dv[o] = sdv[q];
 }
@@ -451,11 +455,11 @@ __global__ void k_update_warp(const double* __restrict__ sdu, const double* __re
 // transposition of the tile was measured slower: the kernel is bound by the 4-tap x C-plane gather of the warp).
 __global__ void k_update_warp_skew(const double2s* __restrict__ pd, double* __restrict__ u, double* __restrict__ v,
                                    const double* __restrict__ im1, const double* __restrict__ im2,
-                                   double* __restrict__ warp, int H, int W, int planes, int nsp) {
+                                   double* __restrict__ warp, int H, int W, int planes, SkewIdx sk) {
     const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
     if (j >= W || i >= H) return;
     const size_t o = (size_t)i * W + j;
-    const double2s c = pd[sor_index<true>(i, j, W, nsp) / 2];
+    const double2s c = pd[skew_cell(i, j, sk)];
     double fu = u[o], fv = v[o];
     fu += c.x;
     fv += c.y;
@@ -648,14 +652,16 @@ int compute_phi(papof_handle* h, const double* u, const double* v, double* phi, 
     return PAPOF_OK;
 }
 
+static SkewIdx skew_idx(const SorPlanes& sp) { return SkewIdx{sp.sd.hp, sp.sd.qt, sp.sd.rt}; }
+
 int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,
                     const double* v, int H, int W, int planes, double alpha, double omega, const SorPlanes& out,
                     double* opt_imdx2, double* opt_imdy2) {
     if (out.skew) {
-        const SkewDims sd = skew_dims(H, W);
-        hipLaunchKernelGGL(k_assemble_skew, dim3((W + kTileJ - 1) / kTileJ, sd.nb), dim3(256), 0, h->stream, blend,
-                           imdt, phi, u, v, H, W, planes, alpha, omega, sd.nsp, (double2s*)out.phi, (double2s*)out.a1,
-                           (double2s*)out.b1, opt_imdx2, opt_imdy2, deriv5_taps());
+        hipLaunchKernelGGL(k_assemble_skew, dim3((W + kTileJ - 1) / kTileJ, (H + kBandRows - 1) / kBandRows),
+                           dim3(256), 0, h->stream, blend, imdt, phi, u, v, H, W, planes, alpha, omega, skew_idx(out),
+                           (double2s*)out.phi, (double2s*)out.a1, (double2s*)out.b1, opt_imdx2, opt_imdy2,
+                           deriv5_taps());
     } else {
         hipLaunchKernelGGL(k_assemble, grid2d(W, H), dim3(BX, BY), 0, h->stream, blend, imdt, phi, u, v, H, W, planes,
                            alpha, omega, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2, opt_imdx2, opt_imdy2,
@@ -674,9 +680,8 @@ int laplacian(papof_handle* h, const double* in, const double* weight, double* o
 int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, const double* im1,
                     const double* im2, double* warp, int H, int W, int planes) {
     if (sp.skew) {
-        const SkewDims sd = skew_dims(H, W);
         hipLaunchKernelGGL(k_update_warp_skew, grid2d(W, H), dim3(BX, BY), 0, h->stream, (const double2s*)sp.du, u, v,
-                           im1, im2, warp, H, W, planes, sd.nsp);
+                           im1, im2, warp, H, W, planes, skew_idx(sp));
     } else {
         hipLaunchKernelGGL(k_update_warp, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, u, v, im1, im2, warp,
                            H, W, planes);
@@ -695,25 +700,25 @@ int bicubic_warp(papof_handle* h, const double* im1, const double* im2, const do
 
 int sor_prep(papof_handle* h, const double* phi, const double* imdxy, const double* imdx2, const double* imdy2,
              const double* rhs1, const double* rhs2, int H, int W, double alpha, double omega, const SorPlanes& out) {
-    const int ns = skew_dims(H, W).nsp;
     if (out.skew)
         hipLaunchKernelGGL(k_sor_prep<true>, grid2d(W, H), dim3(BX, BY), 0, h->stream, phi, imdxy, imdx2, imdy2,
-                           rhs1, rhs2, H, W, alpha, omega, ns, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2);
+                           rhs1, rhs2, H, W, alpha, omega, skew_idx(out), out.phi, out.xy, out.a1, out.a2, out.b1,
+                           out.b2);
     else
         hipLaunchKernelGGL(k_sor_prep<false>, grid2d(W, H), dim3(BX, BY), 0, h->stream, phi, imdxy, imdx2, imdy2,
-                           rhs1, rhs2, H, W, alpha, omega, ns, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2);
+                           rhs1, rhs2, H, W, alpha, omega, SkewIdx{0, 0, 0}, out.phi, out.xy, out.a1, out.a2, out.b1,
+                           out.b2);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
 
 int sor_unpack(papof_handle* h, const SorPlanes& sp, double* du, double* dv, int H, int W) {
-    const int ns = skew_dims(H, W).nsp;
     if (sp.skew)
         hipLaunchKernelGGL(k_sor_unpack<true>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, du, dv, H, W,
-                           ns);
+                           skew_idx(sp));
     else
         hipLaunchKernelGGL(k_sor_unpack<false>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, du, dv, H,
-                           W, ns);
+                           W, SkewIdx{0, 0, 0});
     LAUNCH_CHECK();
     return PAPOF_OK;
 }

@@ -16,26 +16,32 @@
 // PAPOF_SOR_EXACT -- bit-compatible with the reference.  In-place Gauss-Seidel order is kept EXACTLY
 //   by a wavefront-parallel hyperplane schedule: cell (i, j, sweep k) may run once
 //   (i, j-1, k), (i-1, j, k), (i, j+1, k-1), (i+1, j, k-1) are done.
-//     * BAND  = 64 consecutive rows; TASK = (band b, sweep k) = one wavefront, lane r <-> row 64b + r;
-//     * at STEP s lane r updates column j = s - r (the lane above runs one column ahead), NS = W + 63 steps;
-//     * operands live in the per-band SKEWED layout ((b*NS + j + r)*64 + r): at step s the 64 lanes touch
-//       64 consecutive doubles = one fully coalesced 512-byte access per operand;
-//     * left-new is the lane's own previous result, up-new the previous result of lane r-1, down-old the
-//       pending centre of lane r+1 (cross-lane moves); right-old is loaded and becomes the next centre;
-//       lane 0 / lane 63 fetch their up / down neighbours from the adjacent bands' planes;
-//     * all nb * n_sor tasks are launched at once (one 64-thread workgroup each; at most a few hundred
-//       waves, far below the chip's 8192 wave slots, so all are co-resident) and pipeline through
-//       per-task progress counters:  before steps [s0, s1) task (b, k) waits for
-//           prog[k-1][b]   >= min(NS, s1 + 1)      own band, previous sweep (centre / right-old)
-//           prog[k][b-1]   >= min(NS, s1 + 63)     band above, this sweep   (row 63 = up-new of lane 0)
-//           prog[k-1][b+1] >= min(NS, s1 - 63)     band below, previous sweep (row 0 = down-old of lane 63)
-//         and publishes prog[k][b] = s1 afterwards.  A waiter only ever waits on lower block indices.
-//       The model in tests/sim_sor_wave.py executes this exact dataflow under a random scheduler and is
-//       checked bit-for-bit against the oracle on the CPU.
-//     * cross-workgroup visibility follows MI355X guide G16/R1: du/dv are stored write-through
-//       (agent-scope relaxed atomics => `sc1`), every publishing wave drains `s_waitcnt vmcnt(0)` before
-//       its one-lane relaxed agent-scope counter store; consumers poll the counter relaxed, then read
-//       du/dv only with agent-scope (`sc1`, L1-bypassing) loads.  Counters are zeroed by a memset node
+//     * TASK = (band b, sweep k) = one wavefront.  Bands are TIME-SKEWED: at sweep k band b owns the 62 rows
+//       62b-k .. 62b-k+61 (lanes 1..62); lanes 0 / 63 are ghost lanes for the row above / below.  Because the bands
+//       climb one row per sweep, the row below a band -- needed with its previous-sweep value -- belonged to the SAME
+//       band one sweep earlier: a task depends only on (b, k-1) and (b-1, k), never on the band below, which removes
+//       one of the two hand-offs from the sweep-to-sweep critical path;
+//     * at STEP s lane l works on column j = s - l (the lane above runs one column ahead), NS = W + 63 steps;
+//     * operands live in four paired, globally skewed planes of 16-byte cells, (i, j) -> (i+j+qt)*hp + i+rt
+//       (common.h): at step s the 64 lanes of a task touch 64 consecutive cells -- one contiguous 1-KiB access per
+//       operand, ghost lanes included (they read the neighbouring rows' cells through the same access; a1 = a2 = 0 and
+//       omega-1 -> 1 make their update a pass-through and they never store).  Non-cells are 0.0, so image borders and
+//       padding need no predicates: the reference's conditional terms become +-0 added in the same order;
+//     * left-new is the lane's own previous result, up-new the previous result of lane l-1, down-old the pending
+//       centre of lane l+1 (DPP wave shifts); right-old is loaded and becomes the next centre;
+//     * every load is issued R = 8 steps before its use (register software pipeline; 5 memory operations per step
+//       keep R <= 12 within gfx9's 6-bit vmcnt);
+//     * all nb * n_sor tasks are launched at once (one 64-thread workgroup each; a few hundred waves, all
+//       co-resident) and pipeline through per-task progress counters (one 128-byte line each).  Before issuing the
+//       loads of steps < e a task waits for
+//           prog[k-1][b] >= min(NS, e + 1)      own band, previous sweep
+//           prog[k][b-1] >= min(NS, e + 63)     band above, this sweep (ghost lane 0)
+//       A waiter only ever waits on lower block indices.  tests/sim_sor_wave.py executes this exact dataflow under
+//       a random scheduler and is checked bit-for-bit against the oracle on the CPU;
+//     * cross-workgroup visibility follows MI355X guide G16/R1: du/dv are stored write-through (`sc1`) and read with
+//       `sc1` loads; a counter only ever advertises steps whose stores are PROVEN complete -- by marker loads that
+//       retire (vmcnt is in order) after them, twice per R steps without draining the pipeline, and by a final
+//       `s_waitcnt vmcnt(0)`; consumers poll relaxed, one iteration ahead.  Counters are zeroed by a memset node
 //       before every launch, every spin is bounded, and a timeout raises an abort word (PAPOF_ETIMEOUT).
 //
 // PAPOF_SOR_REDBLACK / PAPOF_SOR_JACOBI -- one launch per half-sweep / sweep on row-major planes;
@@ -59,7 +65,7 @@ struct ExactArgs {
     double *du, *dv;
     unsigned* prog;   // [n_sor][nb]
     unsigned* abort;  // one word
-    int H, W, nb, ns, nsp, n_sor, chunk;
+    int H, W, nb, ns, hp, npos, qt, rt, n_sor, chunk;
     double nalpha, om1;
 };
 
@@ -192,21 +198,20 @@ struct Task {  // wave-uniform task constants (SGPRs)
 };
 
 // Per-lane ABSOLUTE byte offsets (constant VGPRs); the step index enters only through the uniform soffset
-// s * 1 KiB.  Real lanes (1..62) address their own cell of this band.  Ghost lanes read straight from the
-// neighbouring band's cells instead of keeping mirrored copies:
-//   lane 0  = the row above  = (band b-1, lane 62): column j sits at that band's skew position j + 62
-//   lane 63 = the row below  = (band b+1, lane 1) : column j sits at that band's skew position j + 1
-// and never store.  kOob switches an access off (reads 0.0, drops the store) without touching EXEC.
+// s * hp * 16 (one skew position).  The 64 lanes address 64 consecutive rows of one position; ghost lanes (0, 63)
+// read the neighbouring rows' cells through the same access, get zero (a, b) operands and never store.
+// kOob switches an access off (reads 0.0, drops the store) without touching EXEC.
 struct LaneOffs {
-    unsigned pa;   // (phi, xy) at this lane's column of step s          [ghost above: phi of that row; below: off]
+    unsigned pa;   // (phi, xy) of this lane's cell at step s
     unsigned pbc;  // (a1, a2) and (b1, b2)                              [ghosts: off -> 0 -> pass-through]
-    unsigned pd;   // (du, dv) at the column of step s + 1 (right-old / next centre)
-    unsigned st;   // (du, dv) store at this lane's column of step s     [ghosts: off]
+    unsigned pd;   // (du, dv) one position ahead (right-old / next centre)
+    unsigned st;   // (du, dv) store of this lane's cell at step s       [ghosts: off]
+    unsigned pos;  // bytes per skew position = hp * 16
 };
 
 template <int R, int t>
 __device__ __forceinline__ void load_slot(const Task& T, const LaneOffs& L, int s, Slots<R>& c) {
-    const unsigned off = (unsigned)s * (kLanes * 16u);  // wave-uniform byte offset -> soffset
+    const unsigned off = (unsigned)s * L.pos;  // wave-uniform byte offset -> soffset
     c.pa[t] = __builtin_amdgcn_raw_buffer_load_b128(T.ra, L.pa, off, kAuxPlain);
     c.pb[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rb, L.pbc, off, kAuxPlain);
     c.pc[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rc, L.pbc, off, kAuxPlain);
@@ -245,7 +250,7 @@ __device__ __forceinline__ void step(const ExactArgs& A, const Task& T, const La
     const double duN = om1 * S.duC + pb.x * (pc.x - s1);
     s2 += xy * duN;
     const double dvN = om1 * S.dvC + pb.y * (pc.y - s2);
-    __builtin_amdgcn_raw_buffer_store_b128(as_u4(duN, dvN), T.rd, L.st, (unsigned)s * (kLanes * 16u), kAuxSc1);
+    __builtin_amdgcn_raw_buffer_store_b128(as_u4(duN, dvN), T.rd, L.st, (unsigned)s * L.pos, kAuxSc1);
     S.duL = duN;
     S.dvL = dvN;
     S.phiL = phiC;
@@ -291,20 +296,18 @@ struct Seg<R, t1, t1, DPP> {
 
 // Progress of the three producers of a task, polled together (a missing producer reads as "finished").
 struct Polls {
-    unsigned own, up, dn;
+    unsigned own, up;
 };
-__device__ __forceinline__ Polls poll(unsigned* p_own, unsigned* p_up, unsigned* p_dn, bool prev, bool has_up,
-                                      bool has_dn) {
+__device__ __forceinline__ Polls poll(unsigned* p_own, unsigned* p_up, unsigned* /*p_dn*/, bool prev, bool has_up,
+                                      bool /*has_dn*/) {
     Polls p;
     p.own = prev ? __hip_atomic_load(p_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
     p.up = has_up ? __hip_atomic_load(p_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
-    p.dn = (prev && has_dn) ? __hip_atomic_load(p_dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
     return p;
 }
 // May every load that touches steps < s_end be issued?  (see the dependency table in the file header)
 __device__ __forceinline__ bool covered(const Polls& p, int ns, int s_end) {
-    return p.own >= (unsigned)min(ns, s_end + 1) && p.up >= (unsigned)min(ns, s_end + 63) &&
-           p.dn >= (unsigned)min(ns, max(0, s_end - 60));
+    return p.own >= (unsigned)min(ns, s_end + 1) && p.up >= (unsigned)min(ns, s_end + 63);
 }
 
 // Bounded wave-uniform wait until the producers cover steps < s_end.  false = abort / timeout.
@@ -371,37 +374,27 @@ struct Segments<R, G, G, DPP> {
 template <int R, int G, bool DPP>
 __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     static_assert(R % G == 0, "segments must divide the pipeline depth");
-    const unsigned lane = threadIdx.x, lane16 = lane * 16u;
+    const unsigned lane = threadIdx.x;
     const int task = blockIdx.x;
     const int k = task / A.nb, b = task - k * A.nb;
-    const int ns = A.ns, nsp = A.nsp;
-    const bool has_up = b > 0, has_dn = (b + 1 < A.nb), prev = k > 0;
+    const int ns = A.ns;
+    const bool has_up = b > 0, has_dn = false, prev = k > 0;
     const bool ghost = lane == 0 || lane == kLanes - 1;
     Task T;
-    const unsigned plane_bytes = (unsigned)(((size_t)A.nb * nsp + 1) * kLanes * 16u);
+    const unsigned plane_bytes = (unsigned)(((size_t)A.npos * A.hp + kLanes) * 16u);
     T.ra = __builtin_amdgcn_make_buffer_rsrc((void*)A.phi, 0, plane_bytes, 0x00020000);
     T.rb = __builtin_amdgcn_make_buffer_rsrc((void*)A.a1, 0, plane_bytes, 0x00020000);
     T.rc = __builtin_amdgcn_make_buffer_rsrc((void*)A.b1, 0, plane_bytes, 0x00020000);
     T.rd = __builtin_amdgcn_make_buffer_rsrc((void*)A.du, 0, plane_bytes, 0x00020000);
-    constexpr unsigned kPos = kLanes * 16u;  // bytes per skew position (one 1-KiB wave access)
-    const unsigned band16 = (unsigned)b * (unsigned)nsp * kPos;
-    const unsigned up16 = band16 - (unsigned)nsp * kPos, dn16 = band16 + (unsigned)nsp * kPos;
+    // lane 0 of task (b, k) stands for image row r0 = 62b - k - 1; at step 0 the task sits at position r0 + qt
+    const int r0 = kBandRows * b - k - 1;
     LaneOffs L;
-    L.pa = band16 + lane16;
-    L.pbc = band16 + lane16;
-    L.pd = band16 + kPos + lane16;
-    L.st = band16 + lane16;
-    if (lane == 0) {  // the row above: band b-1, lane 62, column j at position j + 62
-        L.pa = has_up ? up16 + 62u * kPos + 62u * 16u : kOob;
-        L.pd = has_up ? up16 + 63u * kPos + 62u * 16u : kOob;
-        L.pbc = L.st = kOob;
-    }
-    if (lane == kLanes - 1) {  // the row below: band b+1, lane 1, column j at position j + 1; this lane is at
-                               // column s - 63, so its next centre (column s - 62) sits at position s - 61 there
-        L.pa = kOob;
-        L.pd = has_dn ? dn16 - 61u * kPos + 16u : kOob;
-        L.pbc = L.st = kOob;
-    }
+    L.pos = (unsigned)A.hp * 16u;
+    const unsigned base = ((unsigned)(r0 + A.qt) * (unsigned)A.hp + (unsigned)(r0 + A.rt) + lane) * 16u;
+    L.pa = base;
+    L.pd = base + L.pos;
+    L.pbc = ghost ? kOob : base;
+    L.st = ghost ? kOob : base;
     const double om1 = ghost ? 1.0 : A.om1;  // ghost lanes pass their centre value through unchanged
 
     // one 128-byte line per counter: hundreds of waves publish and poll concurrently, and counters sharing a
@@ -421,9 +414,8 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     // themselves are prefetched one segment ahead.
     Polls pl = poll(p_own, p_up, p_dn, prev, has_up, has_dn);
     if (!wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, 2 * R)) return;
-    {  // centre of the first cells: the (du, dv) one skew position before the step-0 right-old
-        const unsigned first = (L.pd == kOob) ? kOob : L.pd - kPos;
-        const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, first, 0, kAuxSc1));
+    {  // centre of the first cells: the (du, dv) of the task's own position at step 0
+        const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, L.pa, 0, kAuxSc1));
         S.duC = c0.x;
         S.dvC = c0.y;
     }
@@ -537,7 +529,9 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
     if (n_sor <= 0) return PAPOF_EINVAL;
     if (mode == PAPOF_SOR_EXACT) {
         if (!sp.skew) return PAPOF_EINVAL;
-        const SkewDims sd = skew_dims(H, W);
+        const SkewDims sd = skew_dims(H, W, n_sor);
+        if (sd.hp != sp.sd.hp || sd.npos != sp.sd.npos || sd.qt != sp.sd.qt || sd.nb != sp.sd.nb || sd.n > sp.cap_cells)
+            return PAPOF_EINVAL;  // sor_bind() must have chosen this layout (the operands were assembled in it)
         if ((sd.n + kLanes) * 16 >= (size_t(1) << 30)) return PAPOF_EINVAL;  // 32-bit byte offsets, see kOob
         const size_t words = (size_t)sd.nb * n_sor * kProgStride + kProgStride;
         if (words > h->sync_cap) {
@@ -569,7 +563,10 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.W = W;
         A.nb = sd.nb;
         A.ns = sd.ns;
-        A.nsp = sd.nsp;
+        A.hp = sd.hp;
+        A.npos = sd.npos;
+        A.qt = sd.qt;
+        A.rt = sd.rt;
         A.n_sor = n_sor;
         A.chunk = 0;
         A.nalpha = nalpha;
@@ -644,19 +641,31 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
 // All skew positions that are not real cells must read as 0.0 (the kernel relies on it instead of predicates).
 // Real cells are rewritten by the assembly kernel each outer iteration and padding is only ever written with
 // zeros, so one memset per (level, plane) suffices.
-int sor_reset_planes(papof_handle* h, const SorPlanes& sp, int H, int W) {
+int sor_reset_planes(papof_handle* h, const SorPlanes& sp) {
     if (!sp.skew) return PAPOF_OK;
-    const size_t bytes = (skew_dims(H, W).n + kLanes) * 16;
+    const size_t bytes = (sp.sd.n + kLanes) * 16;
     double* pairs[4] = {sp.phi, sp.a1, sp.b1, sp.du};
     for (double* p : pairs) PAPOF_HIP(hipMemsetAsync(p, 0, bytes, h->stream));
     return PAPOF_OK;
 }
 
-int sor_alloc_planes(Arena& A, int H, int W, int mode, SorPlanes& sp) {
+int sor_bind(SorPlanes& sp, int H, int W, int n_sor) {
+    if (!sp.skew) return PAPOF_OK;
+    const SkewDims sd = skew_dims(H, W, n_sor);
+    if (sd.n > sp.cap_cells) return PAPOF_ENOMEM;
+    sp.sd = sd;
+    return PAPOF_OK;
+}
+
+int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes& sp) {
     sp.skew = mode == PAPOF_SOR_EXACT;
     sp.du2 = sp.dv2 = nullptr;
+    sp.cap_cells = 0;
+    sp.sd = SkewDims{};
     if (sp.skew) {
-        const size_t n = 2 * (skew_dims(H, W).n + kLanes);  // doubles per paired plane
+        sp.sd = skew_dims(H, W, n_sor_cap);
+        sp.cap_cells = sp.sd.n;
+        const size_t n = 2 * (sp.cap_cells + kLanes);  // doubles per paired plane
         sp.phi = A.f64(n);
         sp.xy = sp.phi ? sp.phi + 1 : nullptr;
         sp.a1 = A.f64(n);

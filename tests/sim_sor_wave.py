@@ -3,22 +3,23 @@
 The kernel keeps the reference's in-place lexicographic sweep order (src/OpticalFlow.cpp:458-505) while running
 thousands of cells concurrently.  Work decomposition, as in the HIP code:
 
-* the image is cut into BANDS of 62 rows; one wavefront executes one TASK = (band b, sweep k); lanes 1..62 carry
-  the band's rows, lane 0 / lane 63 are GHOST lanes standing for the last row of band b-1 / first row of band b+1;
-* at STEP s lane l works on column j = s - l (the lane above is one column ahead), NS = W + 63 steps per task;
-* operands live in per-band SKEWED planes: cell (lane l, column j) of band b at position (b, j + l, l), every
-  position that is not a real cell holds 0.0, so borders need no predicates;
+* one wavefront executes one TASK = (band b, sweep k).  Bands are TIME-SKEWED: at sweep k band b owns the 62 rows
+  62b - k .. 62b - k + 61 (lanes 1..62); lane 0 / lane 63 are GHOST lanes for the row above / below.  Shifting
+  the bands up by one row per sweep makes the row below a band (needed with its previous-sweep value) a row the SAME
+  band owned one sweep earlier, so a task depends only on (b, k-1) and (b-1, k) -- never on the band below;
+* at STEP s lane l works on row 62b - k - 1 + l, column j = s - l (the lane above is one column ahead): NS = W + 63 steps;
+* operands live in GLOBALLY skewed planes: cell (row i, column j) at [position i + j + QT][row i + RT], every
+  position/row that is not a real cell holds 0.0, so borders need no predicates.  The 64 lanes of a task touch 64
+  consecutive rows of one position = one contiguous access, ghost lanes included (they simply read the neighbouring
+  rows' cells; their a1 = a2 = 0 and omega-1 -> 1 turn the update into a pass-through, and they never store);
 * left-new = the lane's own previous result; up-new = previous result of lane l-1; down-old = the pending centre of
-  lane l+1; right-old is LOADED (it becomes the next centre).  Ghost lanes load the neighbour band's cells
-  (band b-1 lane 62 at position +62, band b+1 lane 1 at position -62), pass the value through and never store;
-* every load is issued R steps before its use (software pipeline), in SEGMENTS of H = R/G steps; before a segment
-  [s_lo, s_hi) issues its loads -- which are for steps < s_hi + R =: e -- the task needs
-      prog[k-1][b]   >= min(NS, e + 1)     own band, previous sweep (centre / right-old)
-      prog[k][b-1]   >= min(NS, e + 63)    band above, this sweep   (ghost lane 0)
-      prog[k-1][b+1] >= min(NS, e - 60)    band below, previous sweep (ghost lane 63)
-  and it publishes only steps whose stores are PROVEN complete by the in-order retirement of the memory pipeline:
-  with G = 1 and R >= 8 (the shipped configuration) two marker loads per iteration let it publish i*R + R/2 by the
-  end of iteration i; otherwise s_hi - R at the end of a segment; finally NS after a full drain.
+  lane l+1; right-old is LOADED (it becomes the next centre);
+* every load is issued R steps before its use (software pipeline).  Before iteration i issues its loads -- which are
+  for steps < (i+2)R =: e -- the task needs
+      prog[k-1][b] >= min(NS, e + 1)     own band, previous sweep (centre / right-old / row below)
+      prog[k][b-1] >= min(NS, e + 63)    band above, this sweep   (ghost lane 0)
+  and it publishes only steps whose stores are PROVEN complete by the in-order retirement of the memory pipeline
+  (two marker loads per iteration: i*R + R/2 by the end of iteration i), finally NS after a full drain.
 
 `simulate()` executes exactly that dataflow with numpy (same operation order, no FMA) under a RANDOM task scheduler
 that honours only the progress conditions above, with loads really taken R steps early and publications really
@@ -30,31 +31,27 @@ LANES = 64
 ROWS = LANES - 2
 
 
-def skew_dims(h, w, r=8):
-    nb = (h + ROWS - 1) // ROWS
+def layout(h, w, n_sor, r=8):
+    nb = (h + n_sor - 1 + ROWS - 1) // ROWS
     ns = w + LANES - 1
-    nsp = (ns + 31) // 32 * 32 + 64
-    return nb, ns, nsp
+    rt = n_sor + 1                      # rows of padding above row 0 (bands climb one row per sweep)
+    qt = n_sor + 1                      # positions of padding before position 0
+    hp = (rt + ROWS * nb + 2 + 7) // 8 * 8
+    npos = qt + ns + 2 * r + 2 + ROWS * (nb - 1) + 2
+    return dict(nb=nb, ns=ns, rt=rt, qt=qt, hp=hp, npos=npos)
 
 
-def to_skew(plane, r=8):
+def to_skew(plane, lay):
     h, w = plane.shape
-    nb, ns, nsp = skew_dims(h, w, r)
-    out = np.zeros((nb, nsp + 1, LANES))
-    for i in range(h):
-        b, l = divmod(i, ROWS)
-        l += 1
-        out[b, l:l + w, l] = plane[i]
+    out = np.zeros((lay["npos"], lay["hp"]))
+    ii, jj = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    out[ii + jj + lay["qt"], ii + lay["rt"]] = plane
     return out
 
 
-def from_skew(sk, h, w):
-    out = np.zeros((h, w))
-    for i in range(h):
-        b, l = divmod(i, ROWS)
-        l += 1
-        out[i] = sk[b, l:l + w, l]
-    return out
+def from_skew(sk, h, w, lay):
+    ii, jj = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    return sk[ii + jj + lay["qt"], ii + lay["rt"]]
 
 
 def shift_up(x):
@@ -76,26 +73,23 @@ class Task:
         z = np.zeros(LANES)
         self.duL, self.dvL, self.phiL, self.duC, self.dvC = z.copy(), z.copy(), z.copy(), z.copy(), z.copy()
         self.slots = [None] * r
-        self.pending_pub = 0
 
 
-def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0, g=2):
+def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0):
     """a1 = omega/(imdx2 + alpha*0.05 + coeff), a2 likewise (see sor_coefficients).  Returns du, dv (H x W)."""
     h, w = phi.shape
-    nb, ns, nsp = skew_dims(h, w, r)
-    P = {n: to_skew(p, r) for n, p in dict(phi=phi, xy=imdxy, a1=a1, a2=a2, b1=b1, b2=b2).items()}
-    du = np.zeros((nb, nsp + 1, LANES))  # memset before every solve
-    dv = np.zeros((nb, nsp + 1, LANES))
+    lay = layout(h, w, n_sor, r)
+    nb, ns, rt, qt = lay["nb"], lay["ns"], lay["rt"], lay["qt"]
+    P = {n: to_skew(p, lay) for n, p in dict(phi=phi, xy=imdxy, a1=a1, a2=a2, b1=b1, b2=b2).items()}
+    du = np.zeros((lay["npos"], lay["hp"]))  # memset before every solve
+    dv = np.zeros((lay["npos"], lay["hp"]))
     prog = np.zeros((nb, n_sor), dtype=np.int64)
     nalpha = -alpha
     om1 = np.full(LANES, 1 - omega)
     om1[0] = om1[63] = 1.0
-    lane = np.arange(LANES)
-    real = (lane >= 1) & (lane <= 62)
+    real = np.zeros(LANES, dtype=bool)
+    real[1:63] = True
     n_iter = (ns + r - 1) // r
-    assert r % g == 0
-    hseg = r // g
-    n_seg = n_iter * g
     rng = np.random.default_rng(seed)
 
     def covered(b, k, e):
@@ -104,29 +98,18 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0, g=2):
             ok = ok and prog[b, k - 1] >= min(ns, e + 1)
         if b > 0:
             ok = ok and prog[b - 1, k] >= min(ns, e + 63)
-        if k > 0 and b + 1 < nb:
-            ok = ok and prog[b + 1, k - 1] >= min(ns, max(0, e - 60))
         return ok
 
-    def rd(arr, b, pos, ln):
-        """one cell of a skewed plane; positions outside the band's own range read padding (0)"""
-        if b < 0 or b >= nb or pos < 0 or pos > nsp:
-            return 0.0
-        return arr[b, pos, ln]
+    def window(b, k):
+        r0 = ROWS * b - k - 1  # row of ghost lane 0; lanes 1..62 = rows 62b-k .. 62b-k+61
+        return r0 + qt, slice(r0 + rt, r0 + rt + LANES)  # position of step 0, storage rows of the 64 lanes
 
-    def load_pd(arr, b, pos):
-        """the (du|dv) vector a task of band b loads for skew position `pos`"""
-        v = np.where(real, arr[b, min(pos, nsp), :] if 0 <= pos <= nsp else 0.0, 0.0)
-        v[0] = rd(arr, b - 1, pos + 62, 62) if b > 0 else 0.0
-        v[63] = rd(arr, b + 1, pos - 62, 1) if b + 1 < nb else 0.0
-        return v
-
-    def load_slot(b, s):
-        g = lambda n: np.where(real, P[n][b, s, :] if s <= nsp else 0.0, 0.0)
-        phi_v = g("phi")
-        phi_v[0] = rd(P["phi"], b - 1, s + 62, 62) if b > 0 else 0.0
-        return dict(phi=phi_v, xy=g("xy"), a1=g("a1"), a2=g("a2"), b1=g("b1"), b2=g("b2"),
-                    duR=load_pd(du, b, s + 1), dvR=load_pd(dv, b, s + 1))
+    def load_slot(b, k, s):
+        q0, rows = window(b, k)
+        g = lambda n: P[n][q0 + s, rows].copy()
+        z = lambda n: np.where(real, P[n][q0 + s, rows], 0.0)  # ghost lanes: a = b = 0 (descriptor out of range)
+        return dict(phi=g("phi"), xy=g("xy"), a1=z("a1"), a2=z("a2"), b1=z("b1"), b2=z("b2"),
+                    duR=du[q0 + s + 1, rows].copy(), dvR=dv[q0 + s + 1, rows].copy())
 
     pending = [Task(b, k, r) for k in range(n_sor) for b in range(nb)]
     while pending:
@@ -134,23 +117,22 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0, g=2):
         for ti in rng.permutation(len(pending)):
             t = pending[ti]
             b, k = t.b, t.k
+            q0, rows = window(b, k)
             if t.i < 0:  # prologue: needs coverage of steps < 2R, then the first centre and the first R slots
                 if not covered(b, k, 2 * r):
                     continue
-                t.duC, t.dvC = load_pd(du, b, 0), load_pd(dv, b, 0)
+                t.duC, t.dvC = du[q0, rows].copy(), dv[q0, rows].copy()
                 for s in range(r):
-                    t.slots[s] = load_slot(b, s)
+                    t.slots[s] = load_slot(b, k, s)
                 t.i = 0
                 ran = True
                 break
-            i = t.i  # segment index
-            s_lo, s_hi = i * hseg, (i + 1) * hseg
-            if i > 0 and not covered(b, k, s_hi + r):
+            i = t.i
+            if i > 0 and not covered(b, k, (i + 2) * r):
                 continue
             ran = True
-            for s in range(s_lo, s_hi):
-                tt = s % r
-                c = t.slots[tt]
+            for s in range(i * r, (i + 1) * r):
+                c = t.slots[s % r]
                 duU, dvU, phiU = shift_up(t.duL), shift_up(t.dvL), shift_up(t.phiL)
                 duD, dvD = shift_down(c["duR"]), shift_down(c["dvR"])
                 s1 = t.phiL * t.duL
@@ -167,24 +149,19 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0, g=2):
                 duN = om1 * t.duC + c["a1"] * (c["b1"] - s1)
                 s2 = s2 + c["xy"] * duN
                 dvN = om1 * t.dvC + c["a2"] * (c["b2"] - s2)
-                if s <= nsp:
-                    du[b, s, :] = np.where(real, duN, du[b, s, :])  # ghost lanes never store
-                    dv[b, s, :] = np.where(real, dvN, dv[b, s, :])
+                du[q0 + s, rows] = np.where(real, duN, du[q0 + s, rows])  # ghost lanes never store
+                dv[q0 + s, rows] = np.where(real, dvN, dv[q0 + s, rows])
                 t.duL, t.dvL, t.phiL = duN, dvN, c["phi"]
                 t.duC, t.dvC = c["duR"], c["dvR"]
-                t.slots[tt] = load_slot(b, s + r)  # refill R steps ahead: reads memory NOW
-            if g == 1 and r >= 8:
-                # marker scheme of the kernel: by the end of iteration i it has published i*R + R/2
-                prog[b, k] = min(ns, i * r + r // 2)
-            elif s_hi - r > 0:
-                prog[b, k] = min(ns, s_hi - r)  # lagging publication
+                t.slots[s % r] = load_slot(b, k, s + r)  # refill R steps ahead: reads memory NOW
+            prog[b, k] = min(ns, i * r + r // 2)  # marker scheme: published by the end of iteration i
             t.i += 1
-            if t.i == n_seg:
+            if t.i == n_iter:
                 prog[b, k] = ns
                 pending.pop(ti)
             break
         assert ran, "deadlock in the task graph"
-    return from_skew(du, h, w), from_skew(dv, h, w)
+    return from_skew(du, h, w, lay), from_skew(dv, h, w, lay)
 
 
 def sor_coefficients(phi, imdx2, imdy2, alpha, omega):

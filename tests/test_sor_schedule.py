@@ -24,7 +24,7 @@ def test_wave_schedule_is_bit_exact(oracle, h, w, n_sor, chunk):
     alpha, omega = 0.012, 1.8
     phi, imdxy, imdx2, imdy2, r1, r2 = _planes(h, w, h * 1000 + w)
     a1, a2 = sim.sor_coefficients(phi, imdx2, imdy2, alpha, omega)
-    du, dv = sim.simulate(phi, imdxy, a1, a2, r1, r2, n_sor, alpha, omega, r=chunk, seed=w, g=(1 if chunk == 8 else (2 if chunk % 2 == 0 else 3)))
+    du, dv = sim.simulate(phi, imdxy, a1, a2, r1, r2, n_sor, alpha, omega, r=chunk, seed=w)
     eu, ev = oracle.sor(phi, imdxy, imdx2, imdy2, r1, r2, n_sor, alpha=alpha, omega=omega, mode=0)
     assert np.array_equal(du, eu)
     assert np.array_equal(dv, ev)
@@ -33,4 +33,5 @@ def test_wave_schedule_is_bit_exact(oracle, h, w, n_sor, chunk):
 def test_skew_roundtrip():
     rng = np.random.default_rng(0)
     p = rng.standard_normal((150, 33))
-    assert np.array_equal(sim.from_skew(sim.to_skew(p), 150, 33), p)
+    lay = sim.layout(150, 33, 7)
+    assert np.array_equal(sim.from_skew(sim.to_skew(p, lay), 150, 33, lay), p)
