@@ -126,7 +126,7 @@ struct papof_handle {
     int cu_count = 0;
     bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
     int sor_segments = 1;            // publication / coverage-check segments per R steps
-    int sor_depth = 8;               // software-pipeline depth R (steps) of the exact-order SOR kernel
+    int sor_depth = 10;              // software-pipeline depth R (steps) of the exact-order SOR kernel
 };
 
 namespace papof {
