@@ -124,6 +124,12 @@ struct papof_handle {
     std::vector<hipEvent_t> events;
     size_t events_used = 0;
     int cu_count = 0;
+    // host path (papof_flow): persistent device staging block and pinned bounce buffers
+    double* stage_dev = nullptr;
+    size_t stage_dev_bytes = 0;
+    char* pin = nullptr;
+    size_t pin_bytes = 0;
+    int host_threads = 4;            // threads used to move pageable user buffers to / from the pinned buffers
     bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
     int sor_segments = 1;            // publication / coverage-check segments per R steps
     int sor_depth = 10;              // software-pipeline depth R (steps) of the exact-order SOR kernel

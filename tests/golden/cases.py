@@ -74,10 +74,10 @@ def _e2e(res, levels):
     return run
 
 
-def _sched(res, levels, sched):
+def _sched(res, levels, sched, ratio=0.75, alpha=0.012):
     def run(lib):
         a, b = load_pair(res)
-        vx, vy, wi = lib.coarse2fine_flow_sched(a, b, levels, 0.012, 0.75, *sched)
+        vx, vy, wi = lib.coarse2fine_flow_sched(a, b, levels, alpha, ratio, *sched)
         return {"vx": vx, "vy": vy, "warpI2": wi}
     return run
 
@@ -189,6 +189,10 @@ CASES = {
     "cfg4_1920_L5": _sched("1920", 5, (3, 0, 1, 30, 0)),
     "inner2_240_L3": _sched("240", 3, (4, 1, 2, 12, 3)),
     "gray_240_L3": _gray("240", 3),
+    # other pyramid ratios / alpha (the reference hard-codes 0.75 / 0.012 in Coarse2FineFlow; composed from its
+    # public statics by oracle/ref_driver.cpp::ref_coarse2fine_flow_sched): different Gaussian half-widths and dims
+    "ratio05_240_L3": _sched("240", 3, (3, 1, 1, 10, 2), ratio=0.5),
+    "ratio09_240_L4": _sched("240", 4, (2, 0, 1, 8, 0), ratio=0.9, alpha=0.03),
     "stage_pyramid": stage_pyramid,
     "stage_gaussian": stage_gaussian,
     "stage_resize": stage_resize,

@@ -148,7 +148,8 @@ def test_end_to_end_matches_oracle(gpu, oracle, res, levels):
     assert t[9] > 0
 
 
-@pytest.mark.parametrize("case", ["e2e_1920_L5", "cfg4_1920_L5", "e2e_960_L5", "cfg4_480_L5", "gray_240_L3"])
+@pytest.mark.parametrize("case", ["e2e_1920_L5", "cfg4_1920_L5", "e2e_960_L5", "cfg4_480_L5", "gray_240_L3",
+                                  "ratio05_240_L3", "ratio09_240_L4"])
 def test_end_to_end_matches_reference_golden(gpu, case):
     """Directly against the values the untouched reference produced (strided subsample in golden.npz),
     including the full-size 1920x1080 configurations of BASELINE.json that the oracle would need a minute for."""
@@ -156,6 +157,31 @@ def test_end_to_end_matches_reference_golden(gpu, case):
     got = cases.CASES[case](gpu)
     for k, a in got.items():
         _cmp(case + "/" + k + " vs reference", cases.subsample(a), gold["%s|%s" % (case, k)], TOL_SOLVE)
+
+
+@pytest.mark.parametrize("h,w,levels,kw", [
+    (37, 53, 3, {}),                                            # ragged, smaller than one band
+    (100, 7, 2, {}),                                            # tall and thin
+    (7, 100, 2, {}),                                            # one-band strip
+    (63, 64, 2, dict(n_sor=1, n_sor_per_level=0)),              # single sweep, band boundary at row 62
+    (125, 66, 3, dict(n_sor=61, n_sor_per_level=2)),            # more sweeps than rows per band (bands climb > 62 rows)
+    (90, 120, 4, dict(alpha=0.05, omega=1.3, n_outer=2, n_outer_per_level=2, n_sor=7, n_sor_per_level=5)),
+    (90, 120, 3, dict(ratio=0.5)),                              # other pyramid ratio (different Gaussian half-widths)
+    (90, 120, 3, dict(ratio=0.9)),
+    (90, 120, 3, dict(ratio=0.2)),                              # out of range -> clamped to 0.75 like the reference
+])
+def test_ragged_sizes_and_parameters_match_oracle(gpu, oracle, h, w, levels, kw):
+    from papteam_opticalflow_amd import default_params
+    a, b = cases.load_pair("240")
+    a = np.ascontiguousarray(a[:h, :w])
+    b = np.ascontiguousarray(b[:h, :w])
+    got = gpu.coarse2fine_flow(a, b, levels, default_params(**kw))[:3]
+    p = oracle.default_params()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    want = oracle.coarse2fine_flow(a, b, levels, p)[:3]
+    for name, g, w_ in zip(("vx", "vy", "warpI2"), got, want):
+        _cmp("ragged %dx%d L%d %s %s" % (h, w, levels, kw, name), g, w_, TOL_SOLVE)
 
 
 def test_config4_schedule_and_modes(gpu, oracle):
