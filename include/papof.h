@@ -153,7 +153,7 @@ int papof_stage_laplacian(papof_handle* h, const double* in, const double* weigh
 int papof_stage_sor(papof_handle* h, const double* phi, const double* imdxy, const double* imdx2,
                     const double* imdy2, const double* rhs1, const double* rhs2, int height, int width,
                     double alpha, double omega, int n_sor, int sor_mode, double* du, double* dv);
-/* One pyramid level: OpticalFlow::SmoothFlowSOR, src/OpticalFlow.cpp:238-536 (n_inner must be 1).
+/* One pyramid level: OpticalFlow::SmoothFlowSOR, src/OpticalFlow.cpp:238-536.
  * warp, u, v are in/out. */
 int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2, double* warp, double* u,
                            double* v, int height, int width, int c, double alpha, int n_outer, int n_inner,

@@ -115,7 +115,7 @@ struct Level {
 
 int check_params(const papof_params& P, int levels) {
     if (levels < 1) return PAPOF_EINVAL;
-    if (P.n_inner != 1) return PAPOF_EINVAL;  // the reference hard-codes 1 (src/OpticalFlow.cpp:750)
+    if (P.n_inner < 1) return PAPOF_EINVAL;
     if (P.n_outer + 0 < 1 || P.n_sor < 1 || P.n_outer_per_level < 0 || P.n_sor_per_level < 0) return PAPOF_EINVAL;
     if (P.sor_mode < PAPOF_SOR_EXACT || P.sor_mode > PAPOF_SOR_JACOBI) return PAPOF_EINVAL;
     if (!(P.alpha > 0) || !(P.omega > 0)) return PAPOF_EINVAL;
@@ -196,8 +196,8 @@ int alloc_solve_buffers(Arena& A, int H, int W, int fc, int mode, int n_sor_cap,
 // genInImageMask (:278) and estLaplacianNoise (:530) do not influence the results (the mask
 // is never read; the noise estimate only feeds a `< 1e-20` guard) and are not executed.
 int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* warp, double* u, double* v, int H,
-                int W, int fc, double alpha, int n_outer, int n_sor, double omega, int mode, SolveBuffers& B,
-                PhaseClock& clk, PhaseClock& sorclk) {
+                int W, int fc, double alpha, int n_outer, int n_inner, int n_sor, double omega, int mode,
+                SolveBuffers& B, PhaseClock& clk, PhaseClock& sorclk) {
     const Taps g = smooth5_taps();
     clk.phase(PAPOF_T_PHASE1_GENERATE);
     PAPOF_TRY(filter_h(h, f1, B.tmp, H, W, fc, g));  // smoothed frame 1: constant within the level
@@ -206,14 +206,20 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
         clk.phase(PAPOF_T_PHASE1_GENERATE);
         PAPOF_TRY(filter_h(h, warp, B.tmp, H, W, fc, g));
         PAPOF_TRY(smooth_v_blend(h, B.tmp, B.im1s, B.blend, B.imdt, H, W, fc));
-        clk.phase(PAPOF_T_PHASE2_DERIVATIVES);
-        PAPOF_TRY(compute_phi(h, u, v, B.phi, H, W));
-        clk.phase(PAPOF_T_PHASE4_LINEARSYSTEM);  // psi (Phase3) is fused into the assembly kernel
-        PAPOF_TRY(assemble_system(h, B.blend, B.imdt, B.phi, u, v, H, W, fc, alpha, omega, B.sp, nullptr, nullptr));
-        clk.phase(PAPOF_T_PHASE5_SOR);
-        sorclk.phase(PAPOF_T_PHASE5_SOR);  // always measured: the roofline of the dominant kernel is priced on it
-        PAPOF_TRY(sor_solve(h, B.sp, H, W, alpha, omega, n_sor, mode));
-        sorclk.phase(-1);
+        // inner fixed-point iterations (src/OpticalFlow.cpp:290-506): after the first one, phi is taken at u + du and
+        // psi at imdt + imdx*du + imdy*dv with the increment of the previous solve; the solve itself restarts at 0
+        for (int hh = 0; hh < n_inner; hh++) {
+            const SorPlanes* prev = hh == 0 ? nullptr : &B.sp;
+            clk.phase(PAPOF_T_PHASE2_DERIVATIVES);
+            PAPOF_TRY(compute_phi(h, u, v, prev, B.phi, H, W));
+            clk.phase(PAPOF_T_PHASE4_LINEARSYSTEM);  // psi (Phase3) is fused into the assembly kernel
+            PAPOF_TRY(assemble_system(h, B.blend, B.imdt, B.phi, u, v, H, W, fc, alpha, omega, B.sp, nullptr, nullptr,
+                                      prev));
+            clk.phase(PAPOF_T_PHASE5_SOR);
+            sorclk.phase(PAPOF_T_PHASE5_SOR);  // always measured: the roofline of the dominant kernel is priced on it
+            PAPOF_TRY(sor_solve(h, B.sp, H, W, alpha, omega, n_sor, mode));
+            sorclk.phase(-1);
+        }
         clk.phase(PAPOF_T_PHASE6_UPDATE);
         PAPOF_TRY(update_and_warp(h, B.sp, u, v, f1, f2, warp, H, W, fc));
     }
@@ -295,7 +301,7 @@ int flow_device(papof_handle* h, const double* d_im1, const double* d_im2, int H
         PAPOF_TRY(sor_bind(B.sp, lh, lw, P.n_sor + k * P.n_sor_per_level));
         PAPOF_TRY(sor_reset_planes(h, B.sp));
         PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, lh, lw, fc, P.alpha, P.n_outer + k * P.n_outer_per_level,
-                              P.n_sor + k * P.n_sor_per_level, P.omega, P.sor_mode, B, clk, sorclk));
+                              P.n_inner, P.n_sor + k * P.n_sor_per_level, P.omega, P.sor_mode, B, clk, sorclk));
         pw = lw;
         ph = lh;
     }
@@ -410,8 +416,7 @@ int papof_create(int device, papof_handle** out) {
         return PAPOF_ENODEVICE;
     }
     if (const char* cs = std::getenv("PAPOF_HOST_THREADS")) h->host_threads = std::max(1, std::atoi(cs));
-    if (const char* cs = std::getenv("PAPOF_SOR_DEPTH")) h->sor_depth = std::max(4, std::atoi(cs));
-    if (const char* cs = std::getenv("PAPOF_SOR_SEGS")) h->sor_segments = std::max(1, std::atoi(cs));
+    if (const char* cs = std::getenv("PAPOF_SOR_DEPTH")) h->sor_depth = std::max(8, std::atoi(cs));
     int rc = sor_probe_dpp(h);
     if (rc != PAPOF_OK) {
         papof_destroy(h);
@@ -836,8 +841,8 @@ int papof_stage_linear_system(papof_handle* h, const double* im1, const double* 
     PAPOF_TRY(filter_v(h, tmp, im1s, height, width, c, g));
     PAPOF_TRY(filter_h(h, b, tmp, height, width, c, g));
     PAPOF_TRY(smooth_v_blend(h, tmp, im1s, blend, dt, height, width, c));
-    PAPOF_TRY(compute_phi(h, du, dv, dphi, height, width));
-    PAPOF_TRY(assemble_system(h, blend, dt, dphi, du, dv, height, width, c, alpha, 1.8, sp, x2, y2));
+    PAPOF_TRY(compute_phi(h, du, dv, nullptr, dphi, height, width));
+    PAPOF_TRY(assemble_system(h, blend, dt, dphi, du, dv, height, width, c, alpha, 1.8, sp, x2, y2, nullptr));
     PAPOF_TRY(S.down_planar(dphi, phi, height, width, 1));
     PAPOF_TRY(S.down_planar(sp.xy, imdxy, height, width, 1));
     PAPOF_TRY(S.down_planar(x2, imdx2, height, width, 1));
@@ -902,7 +907,7 @@ int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2
     if (!h || !im1 || !im2 || !warp || !u || !v || height < 1 || width < 1 || c < 1 || n_outer < 1 || n_sor < 1 ||
         sor_mode < PAPOF_SOR_EXACT || sor_mode > PAPOF_SOR_JACOBI)
         return PAPOF_EINVAL;
-    if (n_inner != 1) return PAPOF_EINVAL;
+    if (n_inner < 1) return PAPOF_EINVAL;
     Scope S(h, img_bytes(height, width, c, 12) + img_bytes(height, width, 1, 8) +
                    5 * (skew_dims(height, width, n_sor).n + 128) * 16 + 12 * (size_t)height * width * sizeof(double));
     PAPOF_TRY(S.rc);
@@ -917,8 +922,8 @@ int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2
     PAPOF_TRY(sor_bind(B.sp, height, width, n_sor));
     PAPOF_TRY(sor_reset_planes(h, B.sp));
     PhaseClock clk{h, false}, sorclk{h, false};
-    PAPOF_TRY(smooth_flow(h, f1, f2, w, du, dv, height, width, c, alpha, n_outer, n_sor, omega, sor_mode, B, clk,
-                          sorclk));
+    PAPOF_TRY(smooth_flow(h, f1, f2, w, du, dv, height, width, c, alpha, n_outer, n_inner, n_sor, omega, sor_mode, B,
+                          clk, sorclk));
     PAPOF_TRY(S.down_planar(w, warp, height, width, c));
     PAPOF_TRY(S.down_planar(du, u, height, width, 1));
     PAPOF_TRY(S.down_planar(dv, v, height, width, 1));

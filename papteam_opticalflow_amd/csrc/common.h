@@ -120,7 +120,6 @@ struct papof_handle {
     papof::Arena arena;
     unsigned* sync_words = nullptr;  // progress counters + abort word of the exact-order SOR
     size_t sync_cap = 0;             // in unsigneds
-    unsigned* host_flag = nullptr;   // pinned mirror of the abort word
     std::vector<hipEvent_t> events;
     size_t events_used = 0;
     int cu_count = 0;
@@ -131,7 +130,6 @@ struct papof_handle {
     size_t pin_bytes = 0;
     int host_threads = 4;            // threads used to move pageable user buffers to / from the pinned buffers
     bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
-    int sor_segments = 1;            // publication / coverage-check segments per R steps
     int sor_depth = 10;              // software-pipeline depth R (steps) of the exact-order SOR kernel
 };
 
@@ -149,10 +147,10 @@ int warp_bilinear(papof_handle* h, const double* im1, const double* im2, const d
                   double* out, int H, int W, int planes);
 int smooth_v_blend(papof_handle* h, const double* tmp, const double* im1s, double* blend, double* imdt, int H,
                    int W, int planes);
-int compute_phi(papof_handle* h, const double* u, const double* v, double* phi, int H, int W);
+int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlanes* prev, double* phi, int H, int W);
 int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,
                     const double* v, int H, int W, int planes, double alpha, double omega, const SorPlanes& out,
-                    double* opt_imdx2, double* opt_imdy2);
+                    double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev);
 int laplacian(papof_handle* h, const double* in, const double* weight, double* out, int H, int W);
 int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, const double* im1,
                     const double* im2, double* warp, int H, int W, int planes);

@@ -193,24 +193,6 @@ __global__ void k_smooth_v_blend(const double* __restrict__ tmp, const double* _
     imdt[o] = s2 - s1;
 }
 
-// ------------------------------------------------------------------------------------------------
-// phi, src/OpticalFlow.cpp:295-331: forward differences of the flow (zero in the last column / row,
-// src/Image.h:979-986, :1022-1029) and phi = 0.5/sqrt(ux^2+uy^2+vx^2+vy^2+eps).
-// ------------------------------------------------------------------------------------------------
-__global__ void k_phi(const double* __restrict__ u, const double* __restrict__ v, double* __restrict__ phi, int H,
-                      int W) {
-    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
-    if (j >= W || i >= H) return;
-    const size_t o = (size_t)i * W + j;
-    const double uc = u[o], vc = v[o];
-    const double ux = j < W - 1 ? u[o + 1] - uc : 0.0;
-    const double uy = i < H - 1 ? u[o + W] - uc : 0.0;
-    const double vx = j < W - 1 ? v[o + 1] - vc : 0.0;
-    const double vy = i < H - 1 ? v[o + W] - vc : 0.0;
-    const double t = ux * ux + uy * uy + vx * vx + vy * vy;
-    phi[o] = 0.5 / sqrt(t + 0.001 * 0.001);
-}
-
 // index (in doubles) of cell (i, j) in an SOR operand plane.  Skew mode: paired planes, (phi,xy) (a1,a2) (b1,b2)
 // (du,dv) interleaved, cell (i, j) at (i + j + qt) * hp + (i + rt) -- see common.h.
 struct SkewIdx {
@@ -223,6 +205,71 @@ template <bool SKEW>
 __device__ __forceinline__ size_t sor_index(int i, int j, int W, const SkewIdx& k) {
     if (SKEW) return 2 * skew_cell(i, j, k);
     return (size_t)i * W + j;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The flow increment (du, dv) of the previous inner fixed-point iteration, read where the solver left it
+// (paired skewed plane or two row-major planes).  `du == nullptr` means the first inner iteration: du = dv = 0.
+// ------------------------------------------------------------------------------------------------
+struct Increment {
+    const double *du, *dv;
+    int skew;
+    SkewIdx sk;
+};
+__device__ __forceinline__ void increment_at(const Increment& I, int i, int j, int W, double& du, double& dv) {
+    if (I.du == nullptr) {
+        du = 0.0;
+        dv = 0.0;
+    } else if (I.skew) {
+        const size_t q = 2 * skew_cell(i, j, I.sk);
+        du = I.du[q];
+        dv = I.du[q + 1];
+    } else {
+        du = I.du[(size_t)i * W + j];
+        dv = I.dv[(size_t)i * W + j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// phi, src/OpticalFlow.cpp:295-331: uu = u (+ du after the first inner iteration, :297-303), forward differences
+// (zero in the last column / row, src/Image.h:979-986, :1022-1029), phi = 0.5/sqrt(ux^2+uy^2+vx^2+vy^2+eps).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_phi(const double* __restrict__ u, const double* __restrict__ v, Increment I,
+                      double* __restrict__ phi, int H, int W) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t o = (size_t)i * W + j;
+    double uc = u[o], vc = v[o], ur = 0.0, vr = 0.0, ud = 0.0, vd = 0.0;
+    if (j < W - 1) {
+        ur = u[o + 1];
+        vr = v[o + 1];
+    }
+    if (i < H - 1) {
+        ud = u[o + W];
+        vd = v[o + W];
+    }
+    if (I.du != nullptr) {  // uu = u + du, vv = v + dv (Image::Add, src/Image.h:1857-1877)
+        double a, b;
+        increment_at(I, i, j, W, a, b);
+        uc = uc + a;
+        vc = vc + b;
+        if (j < W - 1) {
+            increment_at(I, i, j + 1, W, a, b);
+            ur = ur + a;
+            vr = vr + b;
+        }
+        if (i < H - 1) {
+            increment_at(I, i + 1, j, W, a, b);
+            ud = ud + a;
+            vd = vd + b;
+        }
+    }
+    const double ux = j < W - 1 ? ur - uc : 0.0;
+    const double uy = i < H - 1 ? ud - uc : 0.0;
+    const double vx = j < W - 1 ? vr - vc : 0.0;
+    const double vy = i < H - 1 ? vd - vc : 0.0;
+    const double t = ux * ux + uy * uy + vx * vx + vy * vy;
+    phi[o] = 0.5 / sqrt(t + 0.001 * 0.001);
 }
 
 // OpticalFlow::Laplacian at one cell, src/OpticalFlow.cpp:641-690: column W-1 receives no horizontal
@@ -284,9 +331,12 @@ struct SystemCell {
 __device__ __forceinline__ SystemCell assemble_cell(const double* __restrict__ blend, const double* __restrict__ imdt,
                                                     const double* __restrict__ phi, const double* __restrict__ u,
                                                     const double* __restrict__ v, int i, int j, int H, int W,
-                                                    int planes, double alpha, double omega, const Taps& d) {
+                                                    int planes, double alpha, double omega, const Taps& d,
+                                                    const Increment& I) {
     const size_t np = (size_t)H * W, o = (size_t)i * W + j;
     double sxy = 0.0, sx2 = 0.0, sy2 = 0.0, stx = 0.0, sty = 0.0;
+    double du, dv;
+    increment_at(I, i, j, W, du, dv);
     for (int k = 0; k < planes; k++) {
         const double* im = blend + k * np;
         double gx = 0.0, gy = 0.0;
@@ -295,7 +345,8 @@ __device__ __forceinline__ SystemCell assemble_cell(const double* __restrict__ b
 #pragma unroll
         for (int l = -2; l <= 2; l++) gy += im[(size_t)clampi(i + l, H) * W + j] * d.t[l + 2];
         const double gt = imdt[k * np + o];
-        double t = gt;  // imdt + imdx*du + imdy*dv with du = dv = 0
+        double t = gt;  // imdt + imdx*du + imdy*dv (src/OpticalFlow.cpp:384); du = dv = 0 in the first inner iteration
+        if (I.du != nullptr) t = gt + gx * du + gy * dv;
         t *= t;
         const double psi = 1 / (2 * sqrt(t + 0.001 * 0.001));
         const double pgx = psi * gx, pgy = psi * gy;
@@ -337,11 +388,11 @@ __global__ void k_assemble(const double* __restrict__ blend, const double* __res
                            const double* __restrict__ v, int H, int W, int planes, double alpha, double omega,
                            double* __restrict__ o_phi, double* __restrict__ o_xy, double* __restrict__ o_a1,
                            double* __restrict__ o_a2, double* __restrict__ o_b1, double* __restrict__ o_b2,
-                           double* __restrict__ o_x2, double* __restrict__ o_y2, Taps d) {
+                           double* __restrict__ o_x2, double* __restrict__ o_y2, Taps d, Increment I) {
     const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
     if (j >= W || i >= H) return;
     const size_t o = (size_t)i * W + j;
-    const SystemCell c = assemble_cell(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d);
+    const SystemCell c = assemble_cell(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I);
     o_phi[o] = c.phi;
     o_xy[o] = c.xy;
     o_a1[o] = c.a1;
@@ -367,14 +418,14 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
                                                        double alpha, double omega, SkewIdx sk,
                                                        double2s* __restrict__ pa, double2s* __restrict__ pb,
                                                        double2s* __restrict__ pc, double* __restrict__ o_x2,
-                                                       double* __restrict__ o_y2, Taps d) {
+                                                       double* __restrict__ o_y2, Taps d, Increment I) {
     __shared__ double stage[6][kBandRows][kTileJ + 1];
     const int b = blockIdx.y, j0 = blockIdx.x * kTileJ, tid = threadIdx.x;
     for (int c = tid; c < kBandRows * kTileJ; c += 256) {
         const int r = c / kTileJ, jj = c - r * kTileJ;
         const int i = b * kBandRows + r, j = j0 + jj;
         if (i < H && j < W) {
-            const SystemCell s = assemble_cell(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d);
+            const SystemCell s = assemble_cell(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I);
             stage[0][r][jj] = s.phi;
             stage[1][r][jj] = s.xy;
             stage[2][r][jj] = s.a1;
@@ -646,26 +697,33 @@ int smooth_v_blend(papof_handle* h, const double* tmp, const double* im1s, doubl
     return PAPOF_OK;
 }
 
-int compute_phi(papof_handle* h, const double* u, const double* v, double* phi, int H, int W) {
-    hipLaunchKernelGGL(k_phi, grid2d(W, H), dim3(BX, BY), 0, h->stream, u, v, phi, H, W);
+static SkewIdx skew_idx(const SorPlanes& sp) { return SkewIdx{sp.sd.hp, sp.sd.qt, sp.sd.rt}; }
+
+// `prev` = operands of the previous inner iteration's solve (nullptr in the first one: du = dv = 0)
+static Increment increment_of(const SorPlanes* prev) {
+    if (!prev) return Increment{nullptr, nullptr, 0, SkewIdx{0, 0, 0}};
+    return Increment{prev->du, prev->dv, prev->skew ? 1 : 0, prev->skew ? skew_idx(*prev) : SkewIdx{0, 0, 0}};
+}
+
+int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlanes* prev, double* phi, int H, int W) {
+    hipLaunchKernelGGL(k_phi, grid2d(W, H), dim3(BX, BY), 0, h->stream, u, v, increment_of(prev), phi, H, W);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
 
-static SkewIdx skew_idx(const SorPlanes& sp) { return SkewIdx{sp.sd.hp, sp.sd.qt, sp.sd.rt}; }
-
 int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,
                     const double* v, int H, int W, int planes, double alpha, double omega, const SorPlanes& out,
-                    double* opt_imdx2, double* opt_imdy2) {
+                    double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev) {
+    const Increment I = increment_of(prev);
     if (out.skew) {
         hipLaunchKernelGGL(k_assemble_skew, dim3((W + kTileJ - 1) / kTileJ, (H + kBandRows - 1) / kBandRows),
                            dim3(256), 0, h->stream, blend, imdt, phi, u, v, H, W, planes, alpha, omega, skew_idx(out),
                            (double2s*)out.phi, (double2s*)out.a1, (double2s*)out.b1, opt_imdx2, opt_imdy2,
-                           deriv5_taps());
+                           deriv5_taps(), I);
     } else {
         hipLaunchKernelGGL(k_assemble, grid2d(W, H), dim3(BX, BY), 0, h->stream, blend, imdt, phi, u, v, H, W, planes,
                            alpha, omega, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2, opt_imdx2, opt_imdy2,
-                           deriv5_taps());
+                           deriv5_taps(), I);
     }
     LAUNCH_CHECK();
     return PAPOF_OK;

@@ -65,7 +65,7 @@ struct ExactArgs {
     double *du, *dv;
     unsigned* prog;   // [n_sor][nb]
     unsigned* abort;  // one word
-    int H, W, nb, ns, hp, npos, qt, rt, n_sor, chunk;
+    int H, W, nb, ns, hp, npos, qt, rt, n_sor;
     double nalpha, om1;
 };
 
@@ -74,23 +74,6 @@ __device__ __forceinline__ double ld_agent(const double* p) {
 }
 __device__ __forceinline__ void st_agent(double* p, double v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Wave-uniform bounded wait for *p >= need.  Returns false on abort/timeout.
-__device__ __forceinline__ bool wait_ge(unsigned* p, unsigned need, unsigned* abort_word) {
-    unsigned spins = 0;
-    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        __builtin_amdgcn_s_sleep(2);
-        ++spins;
-        if ((spins & 255u) == 0u) {
-            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            if (spins > kSpinLimit) {
-                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
-    }
-    return true;
 }
 
 // Cross-lane move of one fp64 value by one lane (the wave-edge lane receives an unspecified value that the
@@ -294,15 +277,18 @@ struct Seg<R, t1, t1, DPP> {
                                                State&) {}
 };
 
-// Progress of the three producers of a task, polled together (a missing producer reads as "finished").
+// Progress of the two producers of a task, polled together (a missing producer reads as "finished").
 struct Polls {
     unsigned own, up;
 };
-__device__ __forceinline__ Polls poll(unsigned* p_own, unsigned* p_up, unsigned* /*p_dn*/, bool prev, bool has_up,
-                                      bool /*has_dn*/) {
+struct Deps {  // wave-uniform
+    unsigned *own, *up;  // counters of (b, k-1) and (b-1, k)
+    bool has_own, has_up;
+};
+__device__ __forceinline__ Polls poll(const Deps& d) {
     Polls p;
-    p.own = prev ? __hip_atomic_load(p_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
-    p.up = has_up ? __hip_atomic_load(p_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
+    p.own = d.has_own ? __hip_atomic_load(d.own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
+    p.up = d.has_up ? __hip_atomic_load(d.up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
     return p;
 }
 // May every load that touches steps < s_end be issued?  (see the dependency table in the file header)
@@ -311,8 +297,7 @@ __device__ __forceinline__ bool covered(const Polls& p, int ns, int s_end) {
 }
 
 // Bounded wave-uniform wait until the producers cover steps < s_end.  false = abort / timeout.
-__device__ __forceinline__ bool wait_covered(const ExactArgs& A, Polls& pl, unsigned* p_own, unsigned* p_up,
-                                             unsigned* p_dn, bool prev, bool has_up, bool has_dn, int s_end) {
+__device__ __forceinline__ bool wait_covered(const ExactArgs& A, Polls& pl, const Deps& d, int s_end) {
     unsigned spins = 0;
     while (!covered(pl, A.ns, s_end)) {
         __builtin_amdgcn_s_sleep(1);
@@ -323,62 +308,19 @@ __device__ __forceinline__ bool wait_covered(const ExactArgs& A, Polls& pl, unsi
                 return false;
             }
         }
-        pl = poll(p_own, p_up, p_dn, prev, has_up, has_dn);
+        pl = poll(d);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler-only: keep the loads below the polls
     return true;
 }
 
-// One segment (H = R/G steps) of an iteration: wait for coverage of the loads it will issue, prefetch the next poll,
-// run the steps, publish what is proven complete.
-template <int R, int G, int g, bool DPP>
-struct Segments {
-    static __device__ __forceinline__ bool run(const ExactArgs& A, const Task& T, const LaneOffs& L, double om1, int i,
-                                               Slots<R>& c, State& S, Polls& pl, unsigned* my_prog, unsigned* p_own,
-                                               unsigned* p_up, unsigned* p_dn, bool prev, bool has_up, bool has_dn,
-                                               bool lane0) {
-        constexpr int H = R / G;
-        const int s_lo = i * R + g * H, s_hi = s_lo + H;
-        // Coverage is checked once per iteration, for all the loads it will issue (those of steps < (i + 2) R):
-        // consuming a poll forces an in-order vmcnt wait on every older load, so finer-grained polling stalls the
-        // pipeline (measured).  Publication below has no such cost and is done every segment.
-        Polls pn = pl;
-        if (g == 0) {
-            if (i > 0 && !wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, (i + 2) * R)) return false;
-            pn = poll(p_own, p_up, p_dn, prev, has_up, has_dn);  // poll for the next iteration
-        }
-        Seg<R, g * H, (g + 1) * H, DPP>::run(A, T, L, om1, i * R, c, S);
-        pl = pn;
-        // Lagged publication without draining the memory pipeline: vmcnt retires in issue order and the slot consumed
-        // by step s was loaded during step s - R *after* that step's store, so having consumed the slot of step
-        // s_hi - 1 proves every store of steps <= s_hi - 1 - R complete.  The asm ties the counter store to the last
-        // consumed operand so the compiler cannot hoist it above that wait.
-        if (s_hi - R > 0) {
-            asm volatile("" ::"v"(S.duL), "v"(S.dvL) : "memory");
-            if (lane0)
-                __hip_atomic_store(my_prog, (unsigned)min(A.ns, s_hi - R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return Segments<R, G, g + 1, DPP>::run(A, T, L, om1, i, c, S, pl, my_prog, p_own, p_up, p_dn, prev, has_up,
-                                               has_dn, lane0);
-    }
-};
-template <int R, int G, bool DPP>
-struct Segments<R, G, G, DPP> {
-    static __device__ __forceinline__ bool run(const ExactArgs&, const Task&, const LaneOffs&, double, int, Slots<R>&,
-                                               State&, Polls&, unsigned*, unsigned*, unsigned*, unsigned*, bool, bool,
-                                               bool, bool) {
-        return true;
-    }
-};
-
-template <int R, int G, bool DPP>
+template <int R, bool DPP>
 __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
-    static_assert(R % G == 0, "segments must divide the pipeline depth");
+    static_assert(R >= 8 && R % 2 == 0, "two markers per iteration, each consumed 3 steps later");
     const unsigned lane = threadIdx.x;
     const int task = blockIdx.x;
     const int k = task / A.nb, b = task - k * A.nb;
     const int ns = A.ns;
-    const bool has_up = b > 0, has_dn = false, prev = k > 0;
     const bool ghost = lane == 0 || lane == kLanes - 1;
     Task T;
     const unsigned plane_bytes = (unsigned)(((size_t)A.npos * A.hp + kLanes) * 16u);
@@ -400,20 +342,22 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     // one 128-byte line per counter: hundreds of waves publish and poll concurrently, and counters sharing a
     // line would serialise at the memory side
     unsigned* const my_prog = A.prog + ((size_t)k * A.nb + b) * kProgStride;
-    unsigned* const p_own = A.prog + ((size_t)(k - 1) * A.nb + b) * kProgStride;
-    unsigned* const p_up = A.prog + ((size_t)k * A.nb + (b - 1)) * kProgStride;
-    unsigned* const p_dn = A.prog + ((size_t)(k - 1) * A.nb + (b + 1)) * kProgStride;
+    Deps D;
+    D.has_own = k > 0;
+    D.has_up = b > 0;
+    D.own = A.prog + ((size_t)(k - 1) * A.nb + b) * kProgStride;
+    D.up = A.prog + ((size_t)k * A.nb + (b - 1)) * kProgStride;
 
-    const int n_iter = (ns + R - 1) / R;  // steps beyond ns only touch padding (nsp >= n_iter*R + R + 1)
+    const int n_iter = (ns + R - 1) / R;  // steps beyond ns only touch padding (npos leaves room for them)
     State S;
     S.duL = S.dvL = S.phiL = 0.0;
     Slots<R> c;
 
-    // Every load must be covered by the producers' published progress before it is issued: the prologue loads steps
-    // < R (+ the refills of the first segment), each segment checks its own refills (Segments::run).  The polls
-    // themselves are prefetched one segment ahead.
-    Polls pl = poll(p_own, p_up, p_dn, prev, has_up, has_dn);
-    if (!wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, 2 * R)) return;
+    // Every load must be covered by the producers' published progress before it is issued.  Iteration i issues the
+    // loads of steps < (i + 2) R; its coverage check uses a poll that was itself issued one iteration earlier
+    // (consuming a poll forces an in-order vmcnt wait on every older load, so finer-grained polling stalls).
+    Polls pl = poll(D);
+    if (!wait_covered(A, pl, D, 2 * R)) return;
     {  // centre of the first cells: the (du, dv) of the task's own position at step 0
         const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, L.pa, 0, kAuxSc1));
         S.duC = c0.x;
@@ -421,40 +365,34 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     }
     Unroll<R, R - 1, DPP>::fill(T, L, c);
 
-    if constexpr (G == 1 && R >= 8) {
-        // MARKER loads: a 4-byte load issued right after the store of some step retires (vmcnt is in order) only
-        // after that store has completed, so consuming it a few steps later proves the step complete and lets the
-        // task publish it without draining the pipeline.  Two markers per iteration (after steps H-1 and R-1),
-        // each consumed D = 3 steps later: published progress lags the real one by 3..7 steps instead of R..2R.
-        constexpr int H = R / 2, D = 3;
-        static_assert(H > D, "marker distance must fit in half an iteration");
-        unsigned mb = 0u;
-        for (int i = 0; i < n_iter; ++i) {
-            if (i > 0 && !wait_covered(A, pl, p_own, p_up, p_dn, prev, has_up, has_dn, (i + 2) * R)) return;
-            const Polls pn = poll(p_own, p_up, p_dn, prev, has_up, has_dn);
-            Seg<R, 0, D, DPP>::run(A, T, L, om1, i * R, c, S);
-            if (i > 0) {  // marker issued after step i*R - 1
-                asm volatile("" ::"v"(mb), "v"(S.duL), "v"(S.dvL) : "memory");
-                if (mb != 0u) return;  // another task raised the abort word
-                if (lane == 0)
-                    __hip_atomic_store(my_prog, (unsigned)min(ns, i * R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            Seg<R, D, H, DPP>::run(A, T, L, om1, i * R, c, S);
-            const unsigned ma = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            Seg<R, H, H + D, DPP>::run(A, T, L, om1, i * R, c, S);
-            asm volatile("" ::"v"(ma), "v"(S.duL), "v"(S.dvL) : "memory");
-            if (ma != 0u) return;
+    // MARKER loads: a 4-byte load issued right after the store of some step retires (vmcnt is in order) only after
+    // that store has completed, so consuming it a few steps later proves the step complete and lets the task
+    // publish it without draining the pipeline.  Two markers per iteration (after steps H-1 and R-1), each consumed
+    // D = 3 steps later: published progress lags the real one by 3..R/2+3 steps.  The marker reads the abort word,
+    // so a raised abort also ends every running task within one iteration.
+    constexpr int H = R / 2, DM = 3;
+    static_assert(H > DM, "marker distance must fit in half an iteration");
+    unsigned mb = 0u;
+    for (int i = 0; i < n_iter; ++i) {
+        if (i > 0 && !wait_covered(A, pl, D, (i + 2) * R)) return;
+        const Polls pn = poll(D);  // poll for iteration i + 1
+        Seg<R, 0, DM, DPP>::run(A, T, L, om1, i * R, c, S);
+        if (i > 0) {  // marker issued after step i*R - 1
+            asm volatile("" ::"v"(mb), "v"(S.duL), "v"(S.dvL) : "memory");
+            if (mb != 0u) return;
             if (lane == 0)
-                __hip_atomic_store(my_prog, (unsigned)min(ns, i * R + H), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            Seg<R, H + D, R, DPP>::run(A, T, L, om1, i * R, c, S);
-            mb = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pl = pn;
+                __hip_atomic_store(my_prog, (unsigned)min(ns, i * R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-    } else {
-        for (int i = 0; i < n_iter; ++i)
-            if (!Segments<R, G, 0, DPP>::run(A, T, L, om1, i, c, S, pl, my_prog, p_own, p_up, p_dn, prev, has_up,
-                                             has_dn, lane == 0))
-                return;
+        Seg<R, DM, H, DPP>::run(A, T, L, om1, i * R, c, S);
+        const unsigned ma = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Seg<R, H, H + DM, DPP>::run(A, T, L, om1, i * R, c, S);
+        asm volatile("" ::"v"(ma), "v"(S.duL), "v"(S.dvL) : "memory");
+        if (ma != 0u) return;
+        if (lane == 0)
+            __hip_atomic_store(my_prog, (unsigned)min(ns, i * R + H), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Seg<R, H + DM, R, DPP>::run(A, T, L, om1, i * R, c, S);
+        mb = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pl = pn;
     }
     // final publication: every store of this wave has left the CU before the counter moves (guide G16/R1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -568,36 +506,20 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.qt = sd.qt;
         A.rt = sd.rt;
         A.n_sor = n_sor;
-        A.chunk = 0;
         A.nalpha = nalpha;
         A.om1 = om1;
         // du = dv = 0 before the first sweep (src/OpticalFlow.cpp:452-453); also clears the ghost-lane mirrors
         PAPOF_HIP(hipMemsetAsync(sp.du, 0, (sd.n + kLanes) * 16, h->stream));
         const dim3 grid(sd.nb * n_sor), block(kLanes);
-        const int R = h->sor_depth, G = h->sor_segments;
-#define PAPOF_LAUNCH_EXACT(RR, GG, DD) hipLaunchKernelGGL((k_sor_exact<RR, GG, DD>), grid, block, 0, h->stream, A)
+        const int R = h->sor_depth;
         if (!h->use_dpp)
-            PAPOF_LAUNCH_EXACT(8, 2, false);
-        else if (R <= 4)
-            PAPOF_LAUNCH_EXACT(4, 2, true);
-        else if (R <= 6) {
-            if (G >= 3)
-                PAPOF_LAUNCH_EXACT(6, 3, true);
-            else
-                PAPOF_LAUNCH_EXACT(6, 2, true);
-        } else if (R <= 8) {
-            if (G >= 4)
-                PAPOF_LAUNCH_EXACT(8, 4, true);
-            else if (G >= 2)
-                PAPOF_LAUNCH_EXACT(8, 2, true);
-            else
-                PAPOF_LAUNCH_EXACT(8, 1, true);
-        } else if (R <= 10) {
-            PAPOF_LAUNCH_EXACT(10, 1, true);
-        } else {
-            PAPOF_LAUNCH_EXACT(12, 1, true);
-        }
-#undef PAPOF_LAUNCH_EXACT
+            hipLaunchKernelGGL((k_sor_exact<8, false>), grid, block, 0, h->stream, A);
+        else if (R <= 8)
+            hipLaunchKernelGGL((k_sor_exact<8, true>), grid, block, 0, h->stream, A);
+        else if (R <= 10)
+            hipLaunchKernelGGL((k_sor_exact<10, true>), grid, block, 0, h->stream, A);
+        else
+            hipLaunchKernelGGL((k_sor_exact<12, true>), grid, block, 0, h->stream, A);
         PAPOF_HIP(hipGetLastError());
         return PAPOF_OK;
     }

@@ -39,7 +39,7 @@ def _cmp(name, got, want, tol):
 
 
 STAGES = ["stage_pyramid", "stage_gaussian", "stage_resize", "stage_im2feature", "stage_warp", "stage_getdxs",
-          "stage_laplacian"]
+          "stage_laplacian", "stage_smoothflow"]  # stage_smoothflow includes nInner = 2 (src/OpticalFlow.cpp:300-304)
 
 
 @pytest.mark.parametrize("case", STAGES)
@@ -121,6 +121,19 @@ def test_sor_throughput_modes_match_oracle_in_same_mode(gpu, oracle, mode, omega
     print("   distance to the exact (reference) order: %.3e" % np.abs(du - xu).max())
 
 
+@pytest.mark.parametrize("mode,omega", [(1, 1.8), (2, 1.0)])
+def test_inner_iterations_in_throughput_modes(gpu, oracle, mode, omega):
+    a, b = cases.load_pair("240")
+    f1 = np.ascontiguousarray(cases.features5(a)[::2, ::2])
+    f2 = np.ascontiguousarray(cases.features5(b)[::2, ::2])
+    h, w, _ = f1.shape
+    z = np.zeros((h, w))
+    got = gpu.smoothflow_sor(f1, f2, f2, z, z, 0.012, 2, 3, 7, omega=omega, mode=mode)
+    want = oracle.smoothflow_sor(f1, f2, f2, z, z, 0.012, 2, 3, 7, omega=omega, mode=mode)
+    for name, g, w_ in zip(("warp", "u", "v"), got, want):
+        _cmp("inner3 mode%d/%s" % (mode, name), g, w_, TOL_SOLVE)
+
+
 @pytest.mark.parametrize("mode,omega", [(0, 1.8), (1, 1.8), (2, 1.0)])
 def test_smoothflow_level_matches_oracle(gpu, oracle, mode, omega):
     a, b = cases.load_pair("240")
@@ -149,7 +162,7 @@ def test_end_to_end_matches_oracle(gpu, oracle, res, levels):
 
 
 @pytest.mark.parametrize("case", ["e2e_1920_L5", "cfg4_1920_L5", "e2e_960_L5", "cfg4_480_L5", "gray_240_L3",
-                                  "ratio05_240_L3", "ratio09_240_L4"])
+                                  "ratio05_240_L3", "ratio09_240_L4", "inner2_240_L3"])
 def test_end_to_end_matches_reference_golden(gpu, case):
     """Directly against the values the untouched reference produced (strided subsample in golden.npz),
     including the full-size 1920x1080 configurations of BASELINE.json that the oracle would need a minute for."""
@@ -212,7 +225,7 @@ def test_invalid_arguments_return_errors(gpu):
     with pytest.raises(PapofError):
         gpu.coarse2fine_flow(a, a, 0)
     with pytest.raises(PapofError):
-        gpu.coarse2fine_flow(a, a, 2, default_params(n_inner=2))
+        gpu.coarse2fine_flow(a, a, 2, default_params(n_inner=0))
     with pytest.raises(PapofError):
         gpu.coarse2fine_flow(a, a, 30)  # pyramid level smaller than one pixel
     with pytest.raises(ValueError):
