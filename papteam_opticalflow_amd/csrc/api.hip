@@ -48,7 +48,7 @@ size_t arena_bytes_for(int H, int W, int C, int levels, int n_sor_max) {
     planes += 8;                           // u, v, resized u, v, phi + slack
     planes += (size_t)3 * C + C;           // bicubic derivative planes + interleaved output
     size_t bytes = planes * np * sizeof(double);
-    bytes += 4 * (sd.n + 2 * kLanes) * 16 + 10 * np * sizeof(double);  // SOR operands: paired skewed planes / row-major
+    bytes += 3 * (sd.n + 2 * kLanes) * 16 + (sd.nd + 2 * kLanes) * 16 + 10 * np * sizeof(double);  // SOR operands
     bytes += (size_t)64 * 4096;            // alignment slack
     return bytes;
 }
@@ -880,7 +880,8 @@ int papof_stage_sor(papof_handle* h, const double* phi, const double* imdxy, con
         n_sor < 1 || sor_mode < PAPOF_SOR_EXACT || sor_mode > PAPOF_SOR_JACOBI)
         return PAPOF_EINVAL;
     const size_t np = (size_t)height * width;
-    Scope S(h, img_bytes(height, width, 1, 16) + 5 * (skew_dims(height, width, n_sor).n + 128) * 16 + 12 * (size_t)height * width * sizeof(double));
+    Scope S(h, img_bytes(height, width, 1, 16) + 4 * (skew_dims(height, width, n_sor).n + 128) * 16 + (skew_dims(height, width, n_sor).nd + 128) * 16 +
+                   12 * (size_t)height * width * sizeof(double));
     PAPOF_TRY(S.rc);
     double* p = S.up_planar(phi, height, width, 1);
     double* xy = S.up_planar(imdxy, height, width, 1);
@@ -909,7 +910,8 @@ int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2
         return PAPOF_EINVAL;
     if (n_inner < 1) return PAPOF_EINVAL;
     Scope S(h, img_bytes(height, width, c, 12) + img_bytes(height, width, 1, 8) +
-                   5 * (skew_dims(height, width, n_sor).n + 128) * 16 + 12 * (size_t)height * width * sizeof(double));
+                   4 * (skew_dims(height, width, n_sor).n + 128) * 16 + (skew_dims(height, width, n_sor).nd + 128) * 16 +
+                   12 * (size_t)height * width * sizeof(double));
     PAPOF_TRY(S.rc);
     double* f1 = S.up_planar(im1, height, width, c);
     double* f2 = S.up_planar(im2, height, width, c);
@@ -961,7 +963,8 @@ int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_m
         sor_mode > PAPOF_SOR_JACOBI)
         return PAPOF_EINVAL;
     const size_t np = (size_t)height * width;
-    Scope S(h, img_bytes(height, width, 1, 16) + 5 * (skew_dims(height, width, n_sor).n + 128) * 16 + 12 * (size_t)height * width * sizeof(double));
+    Scope S(h, img_bytes(height, width, 1, 16) + 4 * (skew_dims(height, width, n_sor).n + 128) * 16 + (skew_dims(height, width, n_sor).nd + 128) * 16 +
+                   12 * (size_t)height * width * sizeof(double));
     PAPOF_TRY(S.rc);
     std::vector<double> host(np * 6);
     std::mt19937_64 rng(seed);

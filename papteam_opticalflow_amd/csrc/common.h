@@ -79,13 +79,21 @@ constexpr int kBandRows = kLanes - 2;  // real rows per task: lanes 1..62; lanes
 // 62b - k .. 62b - k + 61 (bands climb one row per sweep, see sor.hip), so at step s its 64 lanes touch the 64
 // consecutive cells (position 62b - k - 1 + qt + s, rows 62b - k - 1 + rt ...) -- one contiguous 1-KiB access.
 // Every cell that is not a real (row, column) of the image holds 0.0.
+//
+// The unknowns (du, dv) use a different, BANDED PING-PONG layout: D[k & 1][position][band][64 cells] -- task (b, k)
+// writes its 64 lanes at step s to the aligned 1-KiB block D[k & 1][s + 1][b] that no other task of the sweep
+// touches (see sor.hip).  After the last sweep K-1, row i / column j is found at
+//   parity (K-1) & 1, band (i + K-1) / 62, cell c = 1 + (i + K-1) % 62, position j + c + 1.
 struct SkewDims {
     int nb;      // bands = tasks per sweep
     int ns;      // steps per task = W + 63
     int rt, qt;  // padding rows above row 0 / positions before position 0 (n_sor + 1: room for the climbing bands)
     int hp;      // storage rows per position (multiple of 8 => 128-byte aligned positions)
     int npos;    // positions
-    size_t n;    // cells per paired plane
+    size_t n;    // cells per paired coefficient plane
+    int n_sor;   // sweeps this layout was made for
+    int npos_d;  // positions of the (du, dv) planes
+    size_t nd;   // cells of the (du, dv) allocation (both parities)
 };
 inline SkewDims skew_dims(int h, int w, int n_sor) {
     SkewDims d;
@@ -95,6 +103,9 @@ inline SkewDims skew_dims(int h, int w, int n_sor) {
     d.hp = (d.rt + kBandRows * d.nb + 2 + 7) / 8 * 8;
     d.npos = d.qt + d.ns + 2 * kSorMaxDepth + 2 + kBandRows * (d.nb - 1) + 2;
     d.n = (size_t)d.npos * d.hp;
+    d.n_sor = n_sor;
+    d.npos_d = d.ns + 2 * kSorMaxDepth + 4;
+    d.nd = (size_t)2 * d.npos_d * d.nb * kLanes;
     return d;
 }
 
@@ -109,7 +120,7 @@ struct SorPlanes {
     double *du2, *dv2;                     // Jacobi ping-pong (row-major modes only)
     bool skew;
     SkewDims sd;                           // skew mode: layout bound by sor_bind() for (H, W, n_sor) of this solve
-    size_t cap_cells;                      // skew mode: cells each paired plane can hold
+    size_t cap_cells, cap_cells_d;         // skew mode: cells the coefficient planes / the (du, dv) allocation can hold
 };
 
 }  // namespace papof

@@ -196,7 +196,8 @@ __global__ void k_smooth_v_blend(const double* __restrict__ tmp, const double* _
 // index (in doubles) of cell (i, j) in an SOR operand plane.  Skew mode: paired planes, (phi,xy) (a1,a2) (b1,b2)
 // (du,dv) interleaved, cell (i, j) at (i + j + qt) * hp + (i + rt) -- see common.h.
 struct SkewIdx {
-    int hp, qt, rt;
+    int hp, qt, rt;        // coefficient planes
+    int nb, npos_d, klast; // (du, dv) planes: bands, positions, index of the last sweep
 };
 __device__ __forceinline__ size_t skew_cell(int i, int j, const SkewIdx& k) {
     return (size_t)(i + j + k.qt) * k.hp + (size_t)(i + k.rt);
@@ -205,6 +206,12 @@ template <bool SKEW>
 __device__ __forceinline__ size_t sor_index(int i, int j, int W, const SkewIdx& k) {
     if (SKEW) return 2 * skew_cell(i, j, k);
     return (size_t)i * W + j;
+}
+// cell of (du, dv)(i, j) after the last sweep in the banded ping-pong planes (common.h)
+__device__ __forceinline__ size_t dudv_cell(int i, int j, const SkewIdx& k) {
+    const int t = i + k.klast, b = t / kBandRows, c = 1 + (t - b * kBandRows);
+    const size_t parity = (size_t)(k.klast & 1) * k.npos_d * k.nb * kLanes;
+    return parity + ((size_t)(j + c + 1) * k.nb + b) * kLanes + c;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -221,7 +228,7 @@ __device__ __forceinline__ void increment_at(const Increment& I, int i, int j, i
         du = 0.0;
         dv = 0.0;
     } else if (I.skew) {
-        const size_t q = 2 * skew_cell(i, j, I.sk);
+        const size_t q = 2 * dudv_cell(i, j, I.sk);
         du = I.du[q];
         dv = I.du[q + 1];
     } else {
@@ -479,9 +486,15 @@ __global__ void k_sor_unpack(const double* __restrict__ sdu, const double* __res
                              double* __restrict__ du, double* __restrict__ dv, int H, int W, SkewIdx sk) {
     const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
     if (j >= W || i >= H) return;
-    const size_t q = sor_index<SKEW>(i, j, W, sk), o = (size_t)i * W + j;
-    du[o] = sdu[q];
-    dv[o] = sdv[q];
+    const size_t o = (size_t)i * W + j;
+    if (SKEW) {
+        const size_t q = 2 * dudv_cell(i, j, sk);
+        du[o] = sdu[q];
+        dv[o] = sdu[q + 1];
+    } else {
+        du[o] = sdu[o];
+        dv[o] = sdv[o];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -510,7 +523,7 @@ __global__ void k_update_warp_skew(const double2s* __restrict__ pd, double* __re
     const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
     if (j >= W || i >= H) return;
     const size_t o = (size_t)i * W + j;
-    const double2s c = pd[skew_cell(i, j, sk)];
+    const double2s c = pd[dudv_cell(i, j, sk)];
     double fu = u[o], fv = v[o];
     fu += c.x;
     fv += c.y;
@@ -697,12 +710,14 @@ int smooth_v_blend(papof_handle* h, const double* tmp, const double* im1s, doubl
     return PAPOF_OK;
 }
 
-static SkewIdx skew_idx(const SorPlanes& sp) { return SkewIdx{sp.sd.hp, sp.sd.qt, sp.sd.rt}; }
+static SkewIdx skew_idx(const SorPlanes& sp) {
+    return SkewIdx{sp.sd.hp, sp.sd.qt, sp.sd.rt, sp.sd.nb, sp.sd.npos_d, sp.sd.n_sor - 1};
+}
 
 // `prev` = operands of the previous inner iteration's solve (nullptr in the first one: du = dv = 0)
 static Increment increment_of(const SorPlanes* prev) {
-    if (!prev) return Increment{nullptr, nullptr, 0, SkewIdx{0, 0, 0}};
-    return Increment{prev->du, prev->dv, prev->skew ? 1 : 0, prev->skew ? skew_idx(*prev) : SkewIdx{0, 0, 0}};
+    if (!prev) return Increment{nullptr, nullptr, 0, SkewIdx{0, 0, 0, 0, 0, 0}};
+    return Increment{prev->du, prev->dv, prev->skew ? 1 : 0, prev->skew ? skew_idx(*prev) : SkewIdx{0, 0, 0, 0, 0, 0}};
 }
 
 int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlanes* prev, double* phi, int H, int W) {
@@ -764,7 +779,7 @@ int sor_prep(papof_handle* h, const double* phi, const double* imdxy, const doub
                            out.b2);
     else
         hipLaunchKernelGGL(k_sor_prep<false>, grid2d(W, H), dim3(BX, BY), 0, h->stream, phi, imdxy, imdx2, imdy2,
-                           rhs1, rhs2, H, W, alpha, omega, SkewIdx{0, 0, 0}, out.phi, out.xy, out.a1, out.a2, out.b1,
+                           rhs1, rhs2, H, W, alpha, omega, SkewIdx{0, 0, 0, 0, 0, 0}, out.phi, out.xy, out.a1, out.a2, out.b1,
                            out.b2);
     LAUNCH_CHECK();
     return PAPOF_OK;
@@ -776,7 +791,7 @@ int sor_unpack(papof_handle* h, const SorPlanes& sp, double* du, double* dv, int
                            skew_idx(sp));
     else
         hipLaunchKernelGGL(k_sor_unpack<false>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, du, dv, H,
-                           W, SkewIdx{0, 0, 0});
+                           W, SkewIdx{0, 0, 0, 0, 0, 0});
     LAUNCH_CHECK();
     return PAPOF_OK;
 }

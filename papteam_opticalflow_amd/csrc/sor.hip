@@ -22,11 +22,18 @@
 //       band one sweep earlier: a task depends only on (b, k-1) and (b-1, k), never on the band below, which removes
 //       one of the two hand-offs from the sweep-to-sweep critical path;
 //     * at STEP s lane l works on column j = s - l (the lane above runs one column ahead), NS = W + 63 steps;
-//     * operands live in four paired, globally skewed planes of 16-byte cells, (i, j) -> (i+j+qt)*hp + i+rt
-//       (common.h): at step s the 64 lanes of a task touch 64 consecutive cells -- one contiguous 1-KiB access per
-//       operand, ghost lanes included (they read the neighbouring rows' cells through the same access; a1 = a2 = 0 and
-//       omega-1 -> 1 make their update a pass-through and they never store).  Non-cells are 0.0, so image borders and
-//       padding need no predicates: the reference's conditional terms become +-0 added in the same order;
+//     * the six coefficient operands live in three paired, globally skewed planes of 16-byte cells,
+//       (i, j) -> (i+j+qt)*hp + i+rt (common.h): at step s the 64 lanes of a task read 64 consecutive cells -- one
+//       contiguous 1-KiB access per plane, ghost lanes included (a1 = a2 = 0 and omega-1 -> 1 make a ghost's update
+//       a pass-through).  Non-cells are 0.0, so image borders and padding need no predicates: the reference's
+//       conditional terms become +-0 added in the same order;
+//     * the unknowns live in BANDED PING-PONG planes D[k & 1][position][band][64 cells]: at step s task (b, k) stores
+//       all 64 lanes (ghosts store their pass-through) to the aligned 1-KiB block D[k&1][s+1][b], which no other task
+//       of the sweep touches (full-line write-through stores, no sharing of lines between writers), and reads its
+//       old values from D[(k-1)&1][.][b] shifted by one cell (lane l <- cell l-1: the band climbed one row, and
+//       cell 0 is the previous sweep's pass-through of the row above); ghost lane 0 reads the NEW value of the row
+//       above from D[k&1][s+64][b-1][62].  Re-using the parity buffer two sweeps later is a write-after-read on the
+//       block's cell 62 w.r.t. the band below, hence a third, practically never binding dependency (below);
 //     * left-new is the lane's own previous result, up-new the previous result of lane l-1, down-old the pending
 //       centre of lane l+1 (DPP wave shifts); right-old is loaded and becomes the next centre;
 //     * every load is issued R = 8 steps before its use (register software pipeline; 5 memory operations per step
@@ -34,8 +41,9 @@
 //     * all nb * n_sor tasks are launched at once (one 64-thread workgroup each; a few hundred waves, all
 //       co-resident) and pipeline through per-task progress counters (one 128-byte line each).  Before issuing the
 //       loads of steps < e a task waits for
-//           prog[k-1][b] >= min(NS, e + 1)      own band, previous sweep
-//           prog[k][b-1] >= min(NS, e + 63)     band above, this sweep (ghost lane 0)
+//           prog[k-1][b]   >= min(NS, e + 1)      own band, previous sweep
+//           prog[k][b-1]   >= min(NS, e + 63)     band above, this sweep (ghost lane 0)
+//           prog[k-2][b+1] >= min(NS, e - 62)     band below, two sweeps ago (write-after-read of our block)
 //       A waiter only ever waits on lower block indices.  tests/sim_sor_wave.py executes this exact dataflow under
 //       a random scheduler and is checked bit-for-bit against the oracle on the CPU;
 //     * cross-workgroup visibility follows MI355X guide G16/R1: du/dv are stored write-through (`sc1`) and read with
@@ -65,7 +73,7 @@ struct ExactArgs {
     double *du, *dv;
     unsigned* prog;   // [n_sor][nb]
     unsigned* abort;  // one word
-    int H, W, nb, ns, hp, npos, qt, rt, n_sor;
+    int H, W, nb, ns, hp, npos, qt, rt, npos_d, n_sor;
     double nalpha, om1;
 };
 
@@ -173,32 +181,32 @@ constexpr unsigned kOob = 0x80000000u;  // byte offset beyond every plane (sor_s
 template <int R>
 struct Slots {
     u32x4 pa[R], pb[R], pc[R];  // (phi, xy) (a1, a2) (b1, b2) of this lane's cell at skew position s
-    u32x4 pd[R];                // (du, dv) at skew position s + 1: right-old, the next centre
+    u32x4 pd[R];                // (du, dv) right-old of step s (the next centre)
 };
 
 struct Task {  // wave-uniform task constants (SGPRs)
     __amdgpu_buffer_rsrc_t ra, rb, rc, rd;  // descriptors of the four paired planes
 };
 
-// Per-lane ABSOLUTE byte offsets (constant VGPRs); the step index enters only through the uniform soffset
-// s * hp * 16 (one skew position).  The 64 lanes address 64 consecutive rows of one position; ghost lanes (0, 63)
-// read the neighbouring rows' cells through the same access, get zero (a, b) operands and never store.
-// kOob switches an access off (reads 0.0, drops the store) without touching EXEC.
+// Per-lane ABSOLUTE byte offsets (constant VGPRs); the step index enters only through uniform soffsets
+// (s * pos_c for the coefficient planes, s * pos_d for the unknowns).  kOob switches an access off (reads 0.0)
+// without touching EXEC.
 struct LaneOffs {
-    unsigned pa;   // (phi, xy) of this lane's cell at step s
-    unsigned pbc;  // (a1, a2) and (b1, b2)                              [ghosts: off -> 0 -> pass-through]
-    unsigned pd;   // (du, dv) one position ahead (right-old / next centre)
-    unsigned st;   // (du, dv) store of this lane's cell at step s       [ghosts: off]
-    unsigned pos;  // bytes per skew position = hp * 16
+    unsigned pa;     // (phi, xy) of this lane's cell at step s (64 consecutive rows of one skew position)
+    unsigned pbc;    // (a1, a2) and (b1, b2)                     [ghosts: off -> 0 -> pass-through]
+    unsigned pd;     // (du, dv) right-old of step s: own block, previous parity, cell lane-1 [lane 0: block above]
+    unsigned st;     // (du, dv) store of step s: own block, this parity, cell lane (ghosts store their pass-through)
+    unsigned pos_c;  // bytes per coefficient skew position = hp * 16
+    unsigned pos_d;  // bytes per (du, dv) position = nb * 1 KiB
 };
 
 template <int R, int t>
 __device__ __forceinline__ void load_slot(const Task& T, const LaneOffs& L, int s, Slots<R>& c) {
-    const unsigned off = (unsigned)s * L.pos;  // wave-uniform byte offset -> soffset
+    const unsigned off = (unsigned)s * L.pos_c;  // wave-uniform byte offsets -> soffset
     c.pa[t] = __builtin_amdgcn_raw_buffer_load_b128(T.ra, L.pa, off, kAuxPlain);
     c.pb[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rb, L.pbc, off, kAuxPlain);
     c.pc[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rc, L.pbc, off, kAuxPlain);
-    c.pd[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rd, L.pd, off, kAuxSc1);
+    c.pd[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rd, L.pd, (unsigned)s * L.pos_d, kAuxSc1);
 }
 
 struct State {
@@ -233,7 +241,7 @@ __device__ __forceinline__ void step(const ExactArgs& A, const Task& T, const La
     const double duN = om1 * S.duC + pb.x * (pc.x - s1);
     s2 += xy * duN;
     const double dvN = om1 * S.dvC + pb.y * (pc.y - s2);
-    __builtin_amdgcn_raw_buffer_store_b128(as_u4(duN, dvN), T.rd, L.st, (unsigned)s * L.pos, kAuxSc1);
+    __builtin_amdgcn_raw_buffer_store_b128(as_u4(duN, dvN), T.rd, L.st, (unsigned)s * L.pos_d, kAuxSc1);
     S.duL = duN;
     S.dvL = dvN;
     S.phiL = phiC;
@@ -279,21 +287,23 @@ struct Seg<R, t1, t1, DPP> {
 
 // Progress of the two producers of a task, polled together (a missing producer reads as "finished").
 struct Polls {
-    unsigned own, up;
+    unsigned own, up, dn2;
 };
 struct Deps {  // wave-uniform
-    unsigned *own, *up;  // counters of (b, k-1) and (b-1, k)
-    bool has_own, has_up;
+    unsigned *own, *up, *dn2;  // counters of (b, k-1), (b-1, k) and (b+1, k-2)
+    bool has_own, has_up, has_dn2;
 };
 __device__ __forceinline__ Polls poll(const Deps& d) {
     Polls p;
     p.own = d.has_own ? __hip_atomic_load(d.own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
     p.up = d.has_up ? __hip_atomic_load(d.up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
+    p.dn2 = d.has_dn2 ? __hip_atomic_load(d.dn2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
     return p;
 }
 // May every load that touches steps < s_end be issued?  (see the dependency table in the file header)
 __device__ __forceinline__ bool covered(const Polls& p, int ns, int s_end) {
-    return p.own >= (unsigned)min(ns, s_end + 1) && p.up >= (unsigned)min(ns, s_end + 63);
+    return p.own >= (unsigned)min(ns, s_end + 1) && p.up >= (unsigned)min(ns, s_end + 63) &&
+           p.dn2 >= (unsigned)min(ns, max(0, s_end - 62));
 }
 
 // Bounded wave-uniform wait until the producers cover steps < s_end.  false = abort / timeout.
@@ -324,19 +334,26 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     const bool ghost = lane == 0 || lane == kLanes - 1;
     Task T;
     const unsigned plane_bytes = (unsigned)(((size_t)A.npos * A.hp + kLanes) * 16u);
+    constexpr unsigned kBlock = kLanes * 16u;                                  // one task's cells of one position
+    const unsigned par_bytes = (unsigned)A.npos_d * (unsigned)A.nb * kBlock;  // one parity of the (du, dv) planes
     T.ra = __builtin_amdgcn_make_buffer_rsrc((void*)A.phi, 0, plane_bytes, 0x00020000);
     T.rb = __builtin_amdgcn_make_buffer_rsrc((void*)A.a1, 0, plane_bytes, 0x00020000);
     T.rc = __builtin_amdgcn_make_buffer_rsrc((void*)A.b1, 0, plane_bytes, 0x00020000);
-    T.rd = __builtin_amdgcn_make_buffer_rsrc((void*)A.du, 0, plane_bytes, 0x00020000);
+    T.rd = __builtin_amdgcn_make_buffer_rsrc((void*)A.du, 0, 2u * par_bytes, 0x00020000);
     // lane 0 of task (b, k) stands for image row r0 = 62b - k - 1; at step 0 the task sits at position r0 + qt
     const int r0 = kBandRows * b - k - 1;
     LaneOffs L;
-    L.pos = (unsigned)A.hp * 16u;
+    L.pos_c = (unsigned)A.hp * 16u;
+    L.pos_d = (unsigned)A.nb * kBlock;
     const unsigned base = ((unsigned)(r0 + A.qt) * (unsigned)A.hp + (unsigned)(r0 + A.rt) + lane) * 16u;
     L.pa = base;
-    L.pd = base + L.pos;
     L.pbc = ghost ? kOob : base;
-    L.st = ghost ? kOob : base;
+    // (du, dv): the writer of step s uses position s + 1 (position 0 is never written: the centre before step 0)
+    const unsigned mine = (unsigned)(k & 1) * par_bytes, prev = (unsigned)((k + 1) & 1) * par_bytes;
+    L.st = mine + L.pos_d + (unsigned)b * kBlock + lane * 16u;
+    L.pd = prev + L.pos_d + (unsigned)b * kBlock + (lane - 1u) * 16u;  // lanes >= 1: own block, cell lane - 1
+    if (lane == 0)  // the row above, NEW value: block b-1, cell 62, written by (b-1, k) 63 steps ahead of ours
+        L.pd = b > 0 ? mine + 64u * L.pos_d + (unsigned)(b - 1) * kBlock + 62u * 16u : kOob;
     const double om1 = ghost ? 1.0 : A.om1;  // ghost lanes pass their centre value through unchanged
 
     // one 128-byte line per counter: hundreds of waves publish and poll concurrently, and counters sharing a
@@ -345,8 +362,10 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     Deps D;
     D.has_own = k > 0;
     D.has_up = b > 0;
+    D.has_dn2 = k > 1 && b + 1 < A.nb;
     D.own = A.prog + ((size_t)(k - 1) * A.nb + b) * kProgStride;
     D.up = A.prog + ((size_t)k * A.nb + (b - 1)) * kProgStride;
+    D.dn2 = A.prog + ((size_t)(k - 2) * A.nb + (b + 1)) * kProgStride;
 
     const int n_iter = (ns + R - 1) / R;  // steps beyond ns only touch padding (npos leaves room for them)
     State S;
@@ -358,8 +377,9 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     // (consuming a poll forces an in-order vmcnt wait on every older load, so finer-grained polling stalls).
     Polls pl = poll(D);
     if (!wait_covered(A, pl, D, 2 * R)) return;
-    {  // centre of the first cells: the (du, dv) of the task's own position at step 0
-        const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, L.pa, 0, kAuxSc1));
+    {  // centre of the first cells = the right-old of "step -1" (position 0: zero; lane 0: position 63 above)
+        const unsigned first = L.pd == kOob ? kOob : L.pd - L.pos_d;
+        const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, first, 0, kAuxSc1));
         S.duC = c0.x;
         S.dvC = c0.y;
     }
@@ -468,9 +488,11 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
     if (mode == PAPOF_SOR_EXACT) {
         if (!sp.skew) return PAPOF_EINVAL;
         const SkewDims sd = skew_dims(H, W, n_sor);
-        if (sd.hp != sp.sd.hp || sd.npos != sp.sd.npos || sd.qt != sp.sd.qt || sd.nb != sp.sd.nb || sd.n > sp.cap_cells)
+        if (sd.hp != sp.sd.hp || sd.npos != sp.sd.npos || sd.qt != sp.sd.qt || sd.nb != sp.sd.nb ||
+            sd.n_sor != sp.sd.n_sor || sd.n > sp.cap_cells || sd.nd > sp.cap_cells_d)
             return PAPOF_EINVAL;  // sor_bind() must have chosen this layout (the operands were assembled in it)
-        if ((sd.n + kLanes) * 16 >= (size_t(1) << 30)) return PAPOF_EINVAL;  // 32-bit byte offsets, see kOob
+        if ((sd.n + kLanes) * 16 >= (size_t(1) << 30) || sd.nd * 16 >= (size_t(1) << 30))
+            return PAPOF_EINVAL;  // 32-bit byte offsets, see kOob
         const size_t words = (size_t)sd.nb * n_sor * kProgStride + kProgStride;
         if (words > h->sync_cap) {
             PAPOF_HIP(hipStreamSynchronize(h->stream));
@@ -505,11 +527,12 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.npos = sd.npos;
         A.qt = sd.qt;
         A.rt = sd.rt;
+        A.npos_d = sd.npos_d;
         A.n_sor = n_sor;
         A.nalpha = nalpha;
         A.om1 = om1;
         // du = dv = 0 before the first sweep (src/OpticalFlow.cpp:452-453); also clears the ghost-lane mirrors
-        PAPOF_HIP(hipMemsetAsync(sp.du, 0, (sd.n + kLanes) * 16, h->stream));
+        PAPOF_HIP(hipMemsetAsync(sp.du, 0, sd.nd * 16, h->stream));  // both parities
         const dim3 grid(sd.nb * n_sor), block(kLanes);
         const int R = h->sor_depth;
         if (!h->use_dpp)
@@ -566,15 +589,15 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
 int sor_reset_planes(papof_handle* h, const SorPlanes& sp) {
     if (!sp.skew) return PAPOF_OK;
     const size_t bytes = (sp.sd.n + kLanes) * 16;
-    double* pairs[4] = {sp.phi, sp.a1, sp.b1, sp.du};
+    double* pairs[3] = {sp.phi, sp.a1, sp.b1};
     for (double* p : pairs) PAPOF_HIP(hipMemsetAsync(p, 0, bytes, h->stream));
-    return PAPOF_OK;
+    return PAPOF_OK;  // the (du, dv) planes are cleared by every solve
 }
 
 int sor_bind(SorPlanes& sp, int H, int W, int n_sor) {
     if (!sp.skew) return PAPOF_OK;
     const SkewDims sd = skew_dims(H, W, n_sor);
-    if (sd.n > sp.cap_cells) return PAPOF_ENOMEM;
+    if (sd.n > sp.cap_cells || sd.nd > sp.cap_cells_d) return PAPOF_ENOMEM;
     sp.sd = sd;
     return PAPOF_OK;
 }
@@ -582,11 +605,12 @@ int sor_bind(SorPlanes& sp, int H, int W, int n_sor) {
 int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes& sp) {
     sp.skew = mode == PAPOF_SOR_EXACT;
     sp.du2 = sp.dv2 = nullptr;
-    sp.cap_cells = 0;
+    sp.cap_cells = sp.cap_cells_d = 0;
     sp.sd = SkewDims{};
     if (sp.skew) {
         sp.sd = skew_dims(H, W, n_sor_cap);
         sp.cap_cells = sp.sd.n;
+        sp.cap_cells_d = sp.sd.nd;
         const size_t n = 2 * (sp.cap_cells + kLanes);  // doubles per paired plane
         sp.phi = A.f64(n);
         sp.xy = sp.phi ? sp.phi + 1 : nullptr;
@@ -594,7 +618,7 @@ int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes&
         sp.a2 = sp.a1 ? sp.a1 + 1 : nullptr;
         sp.b1 = A.f64(n);
         sp.b2 = sp.b1 ? sp.b1 + 1 : nullptr;
-        sp.du = A.f64(n);
+        sp.du = A.f64(2 * (sp.cap_cells_d + kLanes));
         sp.dv = sp.du ? sp.du + 1 : nullptr;
     } else {
         const size_t n = (size_t)H * W;

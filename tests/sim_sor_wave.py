@@ -8,16 +8,23 @@ thousands of cells concurrently.  Work decomposition, as in the H
   the bands up by one row per sweep makes the row below a band (needed with its previous-sweep value) a row the SAME
   band owned one sweep earlier, so a task depends only on (b, k-1) and (b-1, k) -- never on the band below;
 * at STEP s lane l works on row 62b - k - 1 + l, column j = s - l (the lane above is one column ahead): NS = W + 63 steps;
-* operands live in GLOBALLY skewed planes: cell (row i, column j) at [position i + j + QT][row i + RT], every
-  position/row that is not a real cell holds 0.0, so borders need no predicates.  The 64 lanes of a task touch 64
-  consecutive rows of one position = one contiguous access, ghost lanes included (they simply read the neighbouring
-  rows' cells; their a1 = a2 = 0 and omega-1 -> 1 turn the update into a pass-through, and they never store);
+* the six coefficient operands live in GLOBALLY skewed planes: cell (row i, column j) at [position i + j + QT]
+  [row i + RT], every non-cell 0.0, so borders need no predicates; the 64 lanes of a task read 64 consecutive rows of
+  one position (ghost lanes read the neighbouring rows' phi; their a1 = a2 = 0 and omega-1 -> 1 turn the update into
+  a pass-through);
+* the unknowns (du, dv) live in BANDED, PING-PONG planes D[k & 1][position][band][64 cells]: task (b, k) writes, at
+  step s, all 64 lanes (ghosts write their pass-through) to D[k&1][s + 1][b] -- an aligned 1-KiB block that no other
+  task of the sweep touches -- and reads its old values from D[(k-1)&1][.][b] shifted by one cell (lane l <- cell
+  l - 1: the bands climb one row per sweep, and cell 0 is the previous sweep's pass-through of the row above);
+  ghost lane 0 reads the NEW value of the row above from D[k&1][s + 64][b-1][62];
 * left-new = the lane's own previous result; up-new = previous result of lane l-1; down-old = the pending centre of
   lane l+1; right-old is LOADED (it becomes the next centre);
 * every load is issued R steps before its use (software pipeline).  Before iteration i issues its loads -- which are
   for steps < (i+2)R =: e -- the task needs
-      prog[k-1][b] >= min(NS, e + 1)     own band, previous sweep (centre / right-old / row below)
-      prog[k][b-1] >= min(NS, e + 63)    band above, this sweep   (ghost lane 0)
+      prog[k-1][b]   >= min(NS, e + 1)     own band, previous sweep (centre / right-old / row below)
+      prog[k][b-1]   >= min(NS, e + 63)    band above, this sweep   (ghost lane 0)
+      prog[k-2][b+1] >= min(NS, e - 62)    band below, two sweeps ago: it must have read cell 62 of our block before
+                                           this sweep reuses the block (write-after-read; practically never binding)
   and it publishes only steps whose stores are PROVEN complete by the in-order retirement of the memory pipeline
   (two marker loads per iteration: i*R + R/2 by the end of iteration i), finally NS after a full drain.
 
@@ -75,14 +82,14 @@ class Task:
         self.slots = [None] * r
 
 
-def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0):
+def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0, use_dn2=True):
     """a1 = omega/(imdx2 + alpha*0.05 + coeff), a2 likewise (see sor_coefficients).  Returns du, dv (H x W)."""
     h, w = phi.shape
     lay = layout(h, w, n_sor, r)
     nb, ns, rt, qt = lay["nb"], lay["ns"], lay["rt"], lay["qt"]
     P = {n: to_skew(p, lay) for n, p in dict(phi=phi, xy=imdxy, a1=a1, a2=a2, b1=b1, b2=b2).items()}
-    du = np.zeros((lay["npos"], lay["hp"]))  # memset before every solve
-    dv = np.zeros((lay["npos"], lay["hp"]))
+    npos_d = ns + 2 * r + 4
+    D = np.zeros((2, 2, npos_d, nb, LANES))  # [du|dv][parity][position][band][cell]; memset before every solve
     prog = np.zeros((nb, n_sor), dtype=np.int64)
     nalpha = -alpha
     om1 = np.full(LANES, 1 - omega)
@@ -98,18 +105,29 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0):
             ok = ok and prog[b, k - 1] >= min(ns, e + 1)
         if b > 0:
             ok = ok and prog[b - 1, k] >= min(ns, e + 63)
+        if use_dn2 and k > 1 and b + 1 < nb:
+            ok = ok and prog[b + 1, k - 2] >= min(ns, max(0, e - 62))
         return ok
 
     def window(b, k):
         r0 = ROWS * b - k - 1  # row of ghost lane 0; lanes 1..62 = rows 62b-k .. 62b-k+61
-        return r0 + qt, slice(r0 + rt, r0 + rt + LANES)  # position of step 0, storage rows of the 64 lanes
+        return r0 + qt, slice(r0 + rt, r0 + rt + LANES)
+
+    def load_pd(c, b, k, s):
+        """right-old of step s (-1: the first centre): lanes >= 1 <- cells lane-1 of own block, previous parity;
+        lane 0 <- cell 62 of the block above, this parity, 63 positions ahead"""
+        v = np.zeros(LANES)
+        v[1:] = D[c, (k - 1) & 1, s + 1, b, :63]
+        if b > 0 and s + 64 < npos_d:
+            v[0] = D[c, k & 1, s + 64, b - 1, 62]
+        return v
 
     def load_slot(b, k, s):
         q0, rows = window(b, k)
         g = lambda n: P[n][q0 + s, rows].copy()
         z = lambda n: np.where(real, P[n][q0 + s, rows], 0.0)  # ghost lanes: a = b = 0 (descriptor out of range)
         return dict(phi=g("phi"), xy=g("xy"), a1=z("a1"), a2=z("a2"), b1=z("b1"), b2=z("b2"),
-                    duR=du[q0 + s + 1, rows].copy(), dvR=dv[q0 + s + 1, rows].copy())
+                    duR=load_pd(0, b, k, s), dvR=load_pd(1, b, k, s))
 
     pending = [Task(b, k, r) for k in range(n_sor) for b in range(nb)]
     while pending:
@@ -117,11 +135,10 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0):
         for ti in rng.permutation(len(pending)):
             t = pending[ti]
             b, k = t.b, t.k
-            q0, rows = window(b, k)
             if t.i < 0:  # prologue: needs coverage of steps < 2R, then the first centre and the first R slots
                 if not covered(b, k, 2 * r):
                     continue
-                t.duC, t.dvC = du[q0, rows].copy(), dv[q0, rows].copy()
+                t.duC, t.dvC = load_pd(0, b, k, -1), load_pd(1, b, k, -1)
                 for s in range(r):
                     t.slots[s] = load_slot(b, k, s)
                 t.i = 0
@@ -149,8 +166,8 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0):
                 duN = om1 * t.duC + c["a1"] * (c["b1"] - s1)
                 s2 = s2 + c["xy"] * duN
                 dvN = om1 * t.dvC + c["a2"] * (c["b2"] - s2)
-                du[q0 + s, rows] = np.where(real, duN, du[q0 + s, rows])  # ghost lanes never store
-                dv[q0 + s, rows] = np.where(real, dvN, dv[q0 + s, rows])
+                D[0, k & 1, s + 1, b, :] = duN  # all 64 lanes: ghosts store their pass-through
+                D[1, k & 1, s + 1, b, :] = dvN
                 t.duL, t.dvL, t.phiL = duN, dvN, c["phi"]
                 t.duC, t.dvC = c["duR"], c["dvR"]
                 t.slots[s % r] = load_slot(b, k, s + r)  # refill R steps ahead: reads memory NOW
@@ -161,7 +178,11 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0):
                 pending.pop(ti)
             break
         assert ran, "deadlock in the task graph"
-    return from_skew(du, h, w, lay), from_skew(dv, h, w, lay)
+    # read-out: row i of the last sweep K-1 sits in band (i+K-1)//62, cell 1 + (i+K-1)%62, position j + cell + 1
+    kl = n_sor - 1
+    ii, jj = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    bb, cc = (ii + kl) // ROWS, 1 + (ii + kl) % ROWS
+    return D[0, kl & 1, jj + cc + 1, bb, cc], D[1, kl & 1, jj + cc + 1, bb, cc]
 
 
 def sor_coefficients(phi, imdx2, imdy2, alpha, omega):
