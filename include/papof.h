@@ -109,6 +109,36 @@ int papof_flow_device(papof_handle* h, const double* d_im1, const double* d_im2,
                       int pyramid_levels, const papof_params* params, double* d_vx, double* d_vy,
                       double* d_warpI2, double timing_sec[PAPOF_N_TIMERS]);
 
+/* ---- uint8 frames.  The reference's caller decodes a JPEG to uint8 and hands
+ * `im.astype(float) / 255.` to pyflow (Code/Serial/OpticalFlowCalculation.py:65-70); these entry points take the
+ * uint8 samples (HWC interleaved) and do that one IEEE division per sample on the device while the frame is
+ * planarised -- the same bits, 1 byte instead of 8 per sample over PCIe.  Outputs as papof_flow. */
+int papof_flow_u8(papof_handle* h, const unsigned char* im1, const unsigned char* im2, int height, int width,
+                  int c, int pyramid_levels, const papof_params* params, double* vx, double* vy, double* warpI2,
+                  double timing_sec[PAPOF_N_TIMERS]);
+int papof_flow_device_u8(papof_handle* h, const unsigned char* d_im1, const unsigned char* d_im2, int height,
+                         int width, int c, int pyramid_levels, const papof_params* params, double* d_vx,
+                         double* d_vy, double* d_warpI2, double timing_sec[PAPOF_N_TIMERS]);
+
+/* ---- sequence mode.  The reference's TestSuite walks a 102-frame collection as 101
+ * overlapping pairs (Code/Serial/TestSuite.py:69-81: frame n -> n+1, then n+1 -> n+2, ...), rebuilding the
+ * pyramid of every frame twice.  Here the handle keeps the pyramid of the last pushed frame in its arena: each
+ * push uploads ONE frame, builds ONE pyramid and returns the flow from the previous frame to this one --
+ * bit-identical to papof_flow(previous, frame).  *have_flow = 0 for the push that primes a sequence (first push,
+ * after papof_seq_reset, or when shape / levels / ratio differ from the kept frame: a new sequence starts),
+ * 1 otherwise; outputs are written only when *have_flow == 1.  Any other call on the handle ends the sequence. */
+int papof_seq_reset(papof_handle* h);
+int papof_seq_push(papof_handle* h, const double* frame, int height, int width, int c, int pyramid_levels,
+                   const papof_params* params, double* vx, double* vy, double* warpI2,
+                   double timing_sec[PAPOF_N_TIMERS], int* have_flow);
+int papof_seq_push_u8(papof_handle* h, const unsigned char* frame, int height, int width, int c,
+                      int pyramid_levels, const papof_params* params, double* vx, double* vy, double* warpI2,
+                      double timing_sec[PAPOF_N_TIMERS], int* have_flow);
+/* frame already resident in device memory (fp64 HWC, or uint8 HWC when is_u8 != 0) */
+int papof_seq_push_device(papof_handle* h, const void* d_frame, int is_u8, int height, int width, int c,
+                          int pyramid_levels, const papof_params* params, double* d_vx, double* d_vy,
+                          double* d_warpI2, double timing_sec[PAPOF_N_TIMERS], int* have_flow);
+
 /* Device memory helpers for callers without a HIP binding (bench.py, ctypes users). */
 int papof_dev_alloc(papof_handle* h, size_t bytes, void** out);
 int papof_dev_free(papof_handle* h, void* p);

@@ -43,3 +43,43 @@ def coarse2fine_flow(Im1, Im2, pyramidLevels, nCores=1, **solver):
     params = default_params(**solver) if solver else None
     vx, vy, warp, t = _handle().coarse2fine_flow(Im1, Im2, int(pyramidLevels), params)
     return capi.format_timing(t), vx, vy, warp
+
+
+def coarse2fine_flow_u8(Im1, Im2, pyramidLevels, nCores=1, **solver):
+    """Same as coarse2fine_flow for the uint8 arrays `np.array(Image.open(path))` yields: the caller's
+    `astype(float) / 255.` (Code/Serial/OpticalFlowCalculation.py:69-70) is done on the device, bit-identically, so
+    1/8 of the bytes cross PCIe on the way in."""
+    if int(pyramidLevels) < 1:
+        raise ValueError("pyramidLevels must be >= 1")
+    params = default_params(**solver) if solver else None
+    vx, vy, warp, t = _handle().coarse2fine_flow_u8(Im1, Im2, int(pyramidLevels), params)
+    return capi.format_timing(t), vx, vy, warp
+
+
+class FlowSequence:
+    """Flow along a video: `push(frame)` returns None for the first frame, then the reference's 4-tuple for
+    (previous frame -> this frame).  One upload and one pyramid per frame instead of two (the reference's TestSuite
+    walks a 102-frame collection as 101 overlapping pairs, Code/Serial/TestSuite.py:69-81); results are bit-identical
+    to calling coarse2fine_flow on each pair.  Frames may be float64 in [0,1] or uint8."""
+
+    def __init__(self, pyramidLevels, device=None, **solver):
+        import os
+        self.levels = int(pyramidLevels)
+        if self.levels < 1:
+            raise ValueError("pyramidLevels must be >= 1")
+        self.params = default_params(**solver) if solver else None
+        self.gpu = Papof(int(os.environ.get("PAPOF_DEVICE", "0")) if device is None else device)
+        self.gpu.seq_reset()
+
+    def push(self, frame):
+        r = self.gpu.seq_push(frame, self.levels, self.params)
+        if r is None:
+            return None
+        vx, vy, warp, t = r
+        return capi.format_timing(t), vx, vy, warp
+
+    def reset(self):
+        self.gpu.seq_reset()
+
+    def close(self):
+        self.gpu.close()

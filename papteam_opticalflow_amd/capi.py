@@ -43,7 +43,8 @@ SYMBOLS = [
     "papof_stream", "papof_stage_pyramid", "papof_stage_gaussian", "papof_stage_resize_ratio",
     "papof_stage_resize_wh", "papof_stage_im2feature", "papof_stage_warpFL", "papof_stage_getDxs",
     "papof_stage_linear_system", "papof_stage_laplacian", "papof_stage_sor", "papof_stage_smoothflow",
-    "papof_stage_bicubic_warp", "papof_bench_sor",
+    "papof_stage_bicubic_warp", "papof_bench_sor", "papof_flow_u8", "papof_flow_device_u8", "papof_seq_reset",
+    "papof_seq_push", "papof_seq_push_u8", "papof_seq_push_device",
 ]
 
 
@@ -73,6 +74,15 @@ def load():
     L.papof_flow.argtypes = [c_void_p, _D, _D, c_int, c_int, c_int, c_int, PP, _D, _D, _D, _D]
     L.papof_flow_device.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, PP, c_void_p, c_void_p,
                                     c_void_p, _D]
+    _B = ctypes.POINTER(ctypes.c_ubyte)
+    L.papof_flow_u8.argtypes = [c_void_p, _B, _B, c_int, c_int, c_int, c_int, PP, _D, _D, _D, _D]
+    L.papof_flow_device_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, PP, c_void_p,
+                                       c_void_p, c_void_p, _D]
+    L.papof_seq_reset.argtypes = [c_void_p]
+    L.papof_seq_push.argtypes = [c_void_p, _D, c_int, c_int, c_int, c_int, PP, _D, _D, _D, _D, _I]
+    L.papof_seq_push_u8.argtypes = [c_void_p, _B, c_int, c_int, c_int, c_int, PP, _D, _D, _D, _D, _I]
+    L.papof_seq_push_device.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, PP, c_void_p,
+                                        c_void_p, c_void_p, _D, _I]
     L.papof_dev_alloc.argtypes = [c_void_p, ctypes.c_size_t, ctypes.POINTER(c_void_p)]
     L.papof_dev_free.argtypes = [c_void_p, c_void_p]
     L.papof_dev_upload.argtypes = [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]
@@ -122,6 +132,17 @@ def _c(a, ndim=None):
     return a
 
 
+def _pb(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.uint8 or a.ndim != 3:
+        raise ValueError("expected a uint8 H x W x C array, got %s %r" % (a.dtype, a.shape))
+    return a
+
+
 def _chk(rc, what):
     if rc != 0:
         L = load()
@@ -164,6 +185,48 @@ class Papof:
         _chk(self.L.papof_flow(self.h, _p(im1), _p(im2), h, w, c, levels, pp, _p(vx), _p(vy), _p(wi), _p(t)),
              "papof_flow")
         return vx, vy, wi, t
+
+    def coarse2fine_flow_u8(self, im1, im2, levels, params=None):
+        """uint8 HWC frames as decoded from the JPEGs; the `/ 255.` of OpticalFlowCalculation.py:69-70 happens on the
+        device.  Same return as coarse2fine_flow."""
+        im1, im2 = _u8(im1), _u8(im2)
+        if im1.shape != im2.shape:
+            raise ValueError("Im1 %r and Im2 %r differ in shape" % (im1.shape, im2.shape))
+        h, w, c = im1.shape
+        vx, vy, wi, t = np.zeros((h, w)), np.zeros((h, w)), np.zeros((h, w, c)), np.zeros(N_TIMERS)
+        pp = ctypes.byref(params) if params is not None else None
+        _chk(self.L.papof_flow_u8(self.h, _pb(im1), _pb(im2), h, w, c, levels, pp, _p(vx), _p(vy), _p(wi), _p(t)),
+             "papof_flow_u8")
+        return vx, vy, wi, t
+
+    # ---- sequence mode: one upload + one pyramid per frame (TestSuite.py:69-81 walks overlapping pairs) ----------
+    def seq_reset(self):
+        _chk(self.L.papof_seq_reset(self.h), "papof_seq_reset")
+
+    def seq_push(self, frame, levels, params=None):
+        """Push the next frame of a video (float64 in [0,1] or uint8, HWC).  Returns None for the frame that primes
+        the sequence, else (vx, vy, warpI2, timing) of the flow from the previous frame to this one."""
+        u8 = isinstance(frame, np.ndarray) and frame.dtype == np.uint8
+        frame = _u8(frame) if u8 else _c(frame, 3)
+        h, w, c = frame.shape
+        vx, vy, wi, t = np.zeros((h, w)), np.zeros((h, w)), np.zeros((h, w, c)), np.zeros(N_TIMERS)
+        pp = ctypes.byref(params) if params is not None else None
+        have = c_int(0)
+        if u8:
+            _chk(self.L.papof_seq_push_u8(self.h, _pb(frame), h, w, c, levels, pp, _p(vx), _p(vy), _p(wi), _p(t),
+                                          ctypes.byref(have)), "papof_seq_push_u8")
+        else:
+            _chk(self.L.papof_seq_push(self.h, _p(frame), h, w, c, levels, pp, _p(vx), _p(vy), _p(wi), _p(t),
+                                       ctypes.byref(have)), "papof_seq_push")
+        return (vx, vy, wi, t) if have.value else None
+
+    def seq_push_device(self, d_frame, is_u8, h, w, c, levels, params, d_vx, d_vy, d_warp):
+        t = np.zeros(N_TIMERS)
+        have = c_int(0)
+        pp = ctypes.byref(params) if params is not None else None
+        _chk(self.L.papof_seq_push_device(self.h, d_frame, int(is_u8), h, w, c, levels, pp, d_vx, d_vy, d_warp, _p(t),
+                                          ctypes.byref(have)), "papof_seq_push_device")
+        return t if have.value else None
 
     def coarse2fine_flow_sched(self, im1, im2, levels, alpha, ratio, n_outer, outer_step, n_inner, n_sor, sor_step,
                                mode=SOR_EXACT, omega=1.8):

@@ -231,8 +231,33 @@ int feature_channels(int C) { return C == 3 ? 5 : (C == 1 ? 3 : C); }
 
 }  // namespace
 
+// An interleaved HWC frame resident on the device: fp64 in [0,1] (the reference's buffers) or the decoded uint8
+// samples, which are scaled by 1/255 while they are planarised (OpticalFlowCalculation.py:69-70).
+struct FrameIn {
+    const void* d;
+    bool u8;
+};
+int load_frame(papof_handle* h, const FrameIn& f, double* planar, int H, int W, int C) {
+    if (f.u8) return hwc_u8_to_planar(h, static_cast<const unsigned char*>(f.d), planar, H, W, C);
+    return hwc_to_planar(h, static_cast<const double*>(f.d), planar, H, W, C);
+}
+
+// What a call does with the two pyramid slots at the head of the arena (a collection is a
+// 102-frame video walked as 101 overlapping pairs, TestSuite.py:69-81):
+//   kPair     both frames are given; nothing is kept;
+//   kSeqPrime only `a` is given: build its pyramid and keep it (no flow);
+//   kSeqNext  only `b` is given: frame 1 is the pyramid kept by the previous kSeqPrime / kSeqNext call, the pyramid of
+//             `b` is built into the other slot and kept for the next push.
+enum SeqOp { kPair, kSeqPrime, kSeqNext };
+
+bool seq_matches(const papof_handle* h, int H, int W, int C, int levels, double ratio, size_t need) {
+    const papof_handle::Seq& q = h->seq;
+    return q.valid && q.h == H && q.w == W && q.c == C && q.levels == levels && q.ratio == ratio &&
+           q.arena_base == h->arena.base && need <= h->arena.cap;
+}
+
 // The whole call on device-resident buffers.
-int flow_device(papof_handle* h, const double* d_im1, const double* d_im2, int H, int W, int C, int levels,
+int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, int H, int W, int C, int levels,
                 const papof_params& P, double* d_vx, double* d_vy, double* d_warp, double* timing) {
     PAPOF_TRY(check_params(P, levels));
     double ratio = P.ratio;
@@ -241,7 +266,14 @@ int flow_device(papof_handle* h, const double* d_im1, const double* d_im2, int H
     std::vector<PyrPlan> plan;
     PAPOF_TRY(pyramid_plan(H, W, P.ratio, levels, L, plan));
     const int n_sor_max = P.n_sor + (levels - 1) * P.n_sor_per_level;
-    PAPOF_TRY(ensure_arena(h, arena_bytes_for(H, W, C, levels, n_sor_max)));
+    const size_t need = arena_bytes_for(H, W, C, levels, n_sor_max);
+    if (op == kSeqNext && !seq_matches(h, H, W, C, levels, ratio, need)) {
+        g_last_error = "sequence push does not continue the primed sequence (shape, levels, ratio or arena changed)";
+        return PAPOF_EINVAL;
+    }
+    const int slot1 = op == kSeqNext ? h->seq.slot : 0;  // pyramid slot of frame 1
+    h->seq.valid = false;  // re-established below once the kept pyramid is complete
+    PAPOF_TRY(ensure_arena(h, need));
     Arena& A = h->arena;
     A.off = 0;
     A.overflow = false;
@@ -256,16 +288,37 @@ int flow_device(papof_handle* h, const double* d_im1, const double* d_im2, int H
 
     total.phase(PAPOF_T_TOTAL);
     clk.phase(PAPOF_T_CONSTRUCTION);
-    for (int i = 0; i < levels; i++) {
-        L[i].p1 = A.f64((size_t)L[i].w * L[i].h * C);
-        L[i].p2 = A.f64((size_t)L[i].w * L[i].h * C);
+    for (int i = 0; i < levels; i++) {  // the two pyramid slots: always the first allocations, at fixed offsets
+        double* slot[2];
+        slot[0] = A.f64((size_t)L[i].w * L[i].h * C);
+        slot[1] = A.f64((size_t)L[i].w * L[i].h * C);
+        L[i].p1 = slot[slot1];
+        L[i].p2 = slot[slot1 ^ 1];
     }
     double* tmp_a = A.f64(np0 * C);
     double* tmp_b = A.f64(np0 * C);
     if (A.overflow) return PAPOF_ENOMEM;
-    PAPOF_TRY(hwc_to_planar(h, d_im1, L[0].p1, H, W, C));
-    PAPOF_TRY(hwc_to_planar(h, d_im2, L[0].p2, H, W, C));
-    PAPOF_TRY(build_pyramid(h, L, plan, C, false, tmp_a, tmp_b));
+    if (op != kSeqNext) {
+        PAPOF_TRY(load_frame(h, fa, L[0].p1, H, W, C));
+        PAPOF_TRY(build_pyramid(h, L, plan, C, false, tmp_a, tmp_b));
+    }
+    const auto keep = [&](int slot) {
+        h->seq.valid = true;
+        h->seq.h = H;
+        h->seq.w = W;
+        h->seq.c = C;
+        h->seq.levels = levels;
+        h->seq.ratio = ratio;
+        h->seq.slot = slot;
+        h->seq.arena_base = A.base;
+    };
+    if (op == kSeqPrime) {
+        PAPOF_HIP(hipStreamSynchronize(h->stream));
+        keep(slot1);
+        if (timing) std::memset(timing, 0, sizeof tm);
+        return PAPOF_OK;
+    }
+    PAPOF_TRY(load_frame(h, fb, L[0].p2, H, W, C));
     PAPOF_TRY(build_pyramid(h, L, plan, C, true, tmp_a, tmp_b));
 
     double* f1 = A.f64(np0 * fc);
@@ -329,6 +382,7 @@ int flow_device(papof_handle* h, const double* d_im1, const double* d_im2, int H
     sorclk.collect(tm);
     total.collect(tm);
     if (timing) std::memcpy(timing, tm, sizeof tm);
+    if (op == kSeqNext) keep(slot1 ^ 1);  // the frame just solved against becomes frame 1 of the next push
     return PAPOF_OK;
 }
 
@@ -475,18 +529,69 @@ int papof_dev_download(papof_handle* h, void* dst, const void* src, size_t bytes
     return PAPOF_OK;
 }
 
-int papof_flow_device(papof_handle* h, const double* d_im1, const double* d_im2, int height, int width, int c,
-                      int pyramid_levels, const papof_params* params, double* d_vx, double* d_vy, double* d_warpI2,
-                      double timing_sec[PAPOF_N_TIMERS]) {
-    if (!h || !d_im1 || !d_im2 || !d_vx || !d_vy || !d_warpI2 || height < 1 || width < 1 || c < 1)
-        return PAPOF_EINVAL;
+namespace {
+
+int device_call(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, int height, int width, int c,
+                int pyramid_levels, const papof_params* params, double* d_vx, double* d_vy, double* d_warpI2,
+                double* timing_sec) {
+    if (!h || height < 1 || width < 1 || c < 1) return PAPOF_EINVAL;
+    if (op != kSeqNext && !fa.d) return PAPOF_EINVAL;
+    if (op != kSeqPrime && (!fb.d || !d_vx || !d_vy || !d_warpI2)) return PAPOF_EINVAL;
     papof_params P;
     if (params)
         P = *params;
     else
         papof_default_params(&P);
     PAPOF_HIP(hipSetDevice(h->device));
-    return flow_device(h, d_im1, d_im2, height, width, c, pyramid_levels, P, d_vx, d_vy, d_warpI2, timing_sec);
+    return flow_device(h, fa, fb, op, height, width, c, pyramid_levels, P, d_vx, d_vy, d_warpI2, timing_sec);
+}
+
+// prime or continue?  (a push whose shape / plan differs from the kept frame starts a new sequence)
+SeqOp seq_op_for(papof_handle* h, int H, int W, int C, int levels, const papof_params* params) {
+    papof_params P;
+    if (params)
+        P = *params;
+    else
+        papof_default_params(&P);
+    double ratio = P.ratio;
+    if (ratio > 0.98 || ratio < 0.4) ratio = 0.75;
+    if (levels < 1) return kSeqPrime;
+    const size_t need = arena_bytes_for(H, W, C, levels, P.n_sor + (levels - 1) * P.n_sor_per_level);
+    return seq_matches(h, H, W, C, levels, ratio, need) ? kSeqNext : kSeqPrime;
+}
+
+}  // namespace
+
+int papof_flow_device(papof_handle* h, const double* d_im1, const double* d_im2, int height, int width, int c,
+                      int pyramid_levels, const papof_params* params, double* d_vx, double* d_vy, double* d_warpI2,
+                      double timing_sec[PAPOF_N_TIMERS]) {
+    return device_call(h, FrameIn{d_im1, false}, FrameIn{d_im2, false}, kPair, height, width, c, pyramid_levels,
+                       params, d_vx, d_vy, d_warpI2, timing_sec);
+}
+
+int papof_flow_device_u8(papof_handle* h, const unsigned char* d_im1, const unsigned char* d_im2, int height,
+                         int width, int c, int pyramid_levels, const papof_params* params, double* d_vx,
+                         double* d_vy, double* d_warpI2, double timing_sec[PAPOF_N_TIMERS]) {
+    return device_call(h, FrameIn{d_im1, true}, FrameIn{d_im2, true}, kPair, height, width, c, pyramid_levels, params,
+                       d_vx, d_vy, d_warpI2, timing_sec);
+}
+
+int papof_seq_reset(papof_handle* h) {
+    if (!h) return PAPOF_EINVAL;
+    h->seq.valid = false;
+    return PAPOF_OK;
+}
+
+int papof_seq_push_device(papof_handle* h, const void* d_frame, int is_u8, int height, int width, int c,
+                          int pyramid_levels, const papof_params* params, double* d_vx, double* d_vy,
+                          double* d_warpI2, double timing_sec[PAPOF_N_TIMERS], int* have_flow) {
+    if (!h || !d_frame || !have_flow) return PAPOF_EINVAL;
+    *have_flow = 0;
+    const SeqOp op = seq_op_for(h, height, width, c, pyramid_levels, params);
+    const FrameIn f{d_frame, is_u8 != 0};
+    PAPOF_TRY(device_call(h, f, f, op, height, width, c, pyramid_levels, params, d_vx, d_vy, d_warpI2, timing_sec));
+    *have_flow = op == kSeqNext ? 1 : 0;
+    return PAPOF_OK;
 }
 
 namespace {
@@ -549,16 +654,18 @@ int upload_chunked(papof_handle* h, char* dev, const char* user, char* pin, size
     return PAPOF_OK;
 }
 
-}  // namespace
-
-int papof_flow(papof_handle* h, const double* im1, const double* im2, int height, int width, int c,
-               int pyramid_levels, const papof_params* params, double* vx, double* vy, double* warpI2,
-               double timing_sec[PAPOF_N_TIMERS]) {
-    if (!h || !im1 || !im2 || !vx || !vy || !warpI2 || height < 1 || width < 1 || c < 1 || pyramid_levels < 1)
-        return PAPOF_EINVAL;
+// Host buffers in, host buffers out.  `u8`: the frames are uint8 samples (1 byte per sample over PCIe instead of 8).
+// kPair uploads both frames, kSeqPrime only im1 (and returns no flow), kSeqNext only im2.
+int flow_host(papof_handle* h, const void* im1, const void* im2, bool u8, SeqOp op, int height, int width, int c,
+              int pyramid_levels, const papof_params* params, double* vx, double* vy, double* warpI2,
+              double* timing_sec) {
+    if (!h || height < 1 || width < 1 || c < 1 || pyramid_levels < 1) return PAPOF_EINVAL;
+    if (op != kSeqNext && !im1) return PAPOF_EINVAL;
+    if (op != kSeqPrime && (!im2 || !vx || !vy || !warpI2)) return PAPOF_EINVAL;
     const double t0 = wall();
     PAPOF_HIP(hipSetDevice(h->device));
     const size_t np = (size_t)height * width, nb_img = np * c * sizeof(double), nb_flow = np * sizeof(double);
+    const size_t nb_in = np * c * (u8 ? 1 : sizeof(double));
     // device staging for the interleaved frames and results (separate from the arena, which flow_device resets) and a
     // pinned bounce buffer: inputs [im1 | im2], then reused for the outputs [warpI2 | vx | vy]
     const size_t out_bytes = nb_img + 2 * nb_flow;
@@ -570,9 +677,14 @@ int papof_flow(papof_handle* h, const double* im1, const double* im2, int height
     double* dy = dx + np;
     double tm[PAPOF_N_TIMERS];
     std::memset(tm, 0, sizeof tm);
-    PAPOF_TRY(upload_chunked(h, (char*)d1, (const char*)im1, h->pin, nb_img));
-    PAPOF_TRY(upload_chunked(h, (char*)d2, (const char*)im2, h->pin + nb_img, nb_img));
-    PAPOF_TRY(papof_flow_device(h, d1, d2, height, width, c, pyramid_levels, params, dx, dy, dw, tm));
+    if (op != kSeqNext) PAPOF_TRY(upload_chunked(h, (char*)d1, (const char*)im1, h->pin, nb_in));
+    if (op != kSeqPrime) PAPOF_TRY(upload_chunked(h, (char*)d2, (const char*)im2, h->pin + nb_img, nb_in));
+    PAPOF_TRY(device_call(h, FrameIn{d1, u8}, FrameIn{d2, u8}, op, height, width, c, pyramid_levels, params, dx, dy,
+                          dw, tm));
+    if (op == kSeqPrime) {
+        if (timing_sec) std::memcpy(timing_sec, tm, sizeof tm);
+        return PAPOF_OK;
+    }
     // device -> pinned in chunks (dw, dx, dy are contiguous), each chunk handed to the user as soon as it has landed
     {
         const size_t n_chunks = (out_bytes + kChunk - 1) / kChunk;
@@ -607,6 +719,47 @@ int papof_flow(papof_handle* h, const double* im1, const double* im2, int height
     return PAPOF_OK;
 }
 
+}  // namespace
+
+int papof_flow(papof_handle* h, const double* im1, const double* im2, int height, int width, int c,
+               int pyramid_levels, const papof_params* params, double* vx, double* vy, double* warpI2,
+               double timing_sec[PAPOF_N_TIMERS]) {
+    return flow_host(h, im1, im2, false, kPair, height, width, c, pyramid_levels, params, vx, vy, warpI2, timing_sec);
+}
+
+int papof_flow_u8(papof_handle* h, const unsigned char* im1, const unsigned char* im2, int height, int width, int c,
+                  int pyramid_levels, const papof_params* params, double* vx, double* vy, double* warpI2,
+                  double timing_sec[PAPOF_N_TIMERS]) {
+    return flow_host(h, im1, im2, true, kPair, height, width, c, pyramid_levels, params, vx, vy, warpI2, timing_sec);
+}
+
+namespace {
+int seq_push_host(papof_handle* h, const void* frame, bool u8, int height, int width, int c, int pyramid_levels,
+                  const papof_params* params, double* vx, double* vy, double* warpI2, double* timing_sec,
+                  int* have_flow) {
+    if (!h || !frame || !have_flow) return PAPOF_EINVAL;
+    *have_flow = 0;
+    const SeqOp op = seq_op_for(h, height, width, c, pyramid_levels, params);
+    PAPOF_TRY(flow_host(h, frame, frame, u8, op, height, width, c, pyramid_levels, params, vx, vy, warpI2, timing_sec));
+    *have_flow = op == kSeqNext ? 1 : 0;
+    return PAPOF_OK;
+}
+}  // namespace
+
+int papof_seq_push(papof_handle* h, const double* frame, int height, int width, int c, int pyramid_levels,
+                   const papof_params* params, double* vx, double* vy, double* warpI2,
+                   double timing_sec[PAPOF_N_TIMERS], int* have_flow) {
+    return seq_push_host(h, frame, false, height, width, c, pyramid_levels, params, vx, vy, warpI2, timing_sec,
+                         have_flow);
+}
+
+int papof_seq_push_u8(papof_handle* h, const unsigned char* frame, int height, int width, int c, int pyramid_levels,
+                      const papof_params* params, double* vx, double* vy, double* warpI2,
+                      double timing_sec[PAPOF_N_TIMERS], int* have_flow) {
+    return seq_push_host(h, frame, true, height, width, c, pyramid_levels, params, vx, vy, warpI2, timing_sec,
+                         have_flow);
+}
+
 static std::mutex g_default_mu;
 static papof_handle* g_default = nullptr;
 
@@ -639,6 +792,7 @@ struct Scope {  // arena scope + device selection for one stage call
             rc = PAPOF_EDEVICE;
             return;
         }
+        h->seq.valid = false;  // stage calls reuse the arena from offset 0
         rc = ensure_arena(h, bytes + (1 << 20));
         h->arena.off = 0;
         h->arena.overflow = false;

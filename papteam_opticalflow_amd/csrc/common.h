@@ -142,12 +142,21 @@ struct papof_handle {
     int host_threads = 4;            // threads used to move pageable user buffers to / from the pinned buffers
     bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
     int sor_depth = 10;              // software-pipeline depth R (steps) of the exact-order SOR kernel
+    // sequence mode (papof_seq_*): the pyramid of the last pushed frame stays in the arena and becomes "frame 1" of
+    // the next pair.  Valid only while the arena block, the frame shape and the pyramid plan stay the same.
+    struct Seq {
+        bool valid = false;
+        int h = 0, w = 0, c = 0, levels = 0, slot = 0;  // slot: which of the two pyramid slots holds the last frame
+        double ratio = 0;
+        const char* arena_base = nullptr;
+    } seq;
 };
 
 namespace papof {
 
 // ---- kernels.hip: launch wrappers (all asynchronous on h->stream) ----
 int hwc_to_planar(papof_handle* h, const double* hwc, double* planar, int H, int W, int C);
+int hwc_u8_to_planar(papof_handle* h, const unsigned char* hwc, double* planar, int H, int W, int C);
 int planar_to_hwc(papof_handle* h, const double* planar, double* hwc, int H, int W, int C);
 int filter_h(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f);
 int filter_v(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f);

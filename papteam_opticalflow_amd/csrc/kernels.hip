@@ -33,6 +33,16 @@ __global__ void k_hwc_to_planar(const double* __restrict__ hwc, double* __restri
     for (int k = 0; k < C; k++) planar[k * np + o] = hwc[o * C + k];
 }
 
+// uint8 frames (what the caller decodes from JPEG): the caller's `im.astype(float) / 255.` (OpticalFlowCalculation.py:69-70)
+// is done on load -- one IEEE fp64 division per sample, hence the same bits -- so 1 byte per sample crosses PCIe, not 8.
+__global__ void k_hwc_u8_to_planar(const unsigned char* __restrict__ hwc, double* __restrict__ planar, int H, int W,
+                                   int C) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t o = (size_t)i * W + j, np = (size_t)H * W;
+    for (int k = 0; k < C; k++) planar[k * np + o] = (double)hwc[o * C + k] / 255.0;
+}
+
 __global__ void k_planar_to_hwc(const double* __restrict__ planar, double* __restrict__ hwc, int H, int W, int C) {
     const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
     if (j >= W || i >= H) return;
@@ -652,6 +662,12 @@ Taps central3_taps() {  // src/Image.h:2589
 
 int hwc_to_planar(papof_handle* h, const double* hwc, double* planar, int H, int W, int C) {
     hipLaunchKernelGGL(k_hwc_to_planar, grid2d(W, H), dim3(BX, BY), 0, h->stream, hwc, planar, H, W, C);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int hwc_u8_to_planar(papof_handle* h, const unsigned char* hwc, double* planar, int H, int W, int C) {
+    hipLaunchKernelGGL(k_hwc_u8_to_planar, grid2d(W, H), dim3(BX, BY), 0, h->stream, hwc, planar, H, W, C);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }

@@ -201,12 +201,20 @@ struct LaneOffs {
 };
 
 template <int R, int t>
-__device__ __forceinline__ void load_slot(const Task& T, const LaneOffs& L, int s, Slots<R>& c) {
+__device__ __forceinline__ void load_coef(const Task& T, const LaneOffs& L, int s, Slots<R>& c) {
     const unsigned off = (unsigned)s * L.pos_c;  // wave-uniform byte offsets -> soffset
     c.pa[t] = __builtin_amdgcn_raw_buffer_load_b128(T.ra, L.pa, off, kAuxPlain);
     c.pb[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rb, L.pbc, off, kAuxPlain);
     c.pc[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rc, L.pbc, off, kAuxPlain);
+}
+template <int R, int t>
+__device__ __forceinline__ void load_unknowns(const Task& T, const LaneOffs& L, int s, Slots<R>& c) {
     c.pd[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rd, L.pd, (unsigned)s * L.pos_d, kAuxSc1);
+}
+template <int R, int t>
+__device__ __forceinline__ void load_slot(const Task& T, const LaneOffs& L, int s, Slots<R>& c) {
+    load_coef<R, t>(T, L, s, c);
+    load_unknowns<R, t>(T, L, s, c);
 }
 
 struct State {
@@ -258,16 +266,21 @@ struct Unroll {
         Unroll<R, t - 1, DPP>::run(A, T, L, om1, s0, c, S);
         step<R, t, DPP>(A, T, L, om1, s0 + t, c, S);
     }
-    static __device__ __forceinline__ void fill(const Task& T, const LaneOffs& L, Slots<R>& c) {
-        Unroll<R, t - 1, DPP>::fill(T, L, c);
-        load_slot<R, t>(T, L, t, c);
+    static __device__ __forceinline__ void fill_coef(const Task& T, const LaneOffs& L, Slots<R>& c) {
+        Unroll<R, t - 1, DPP>::fill_coef(T, L, c);
+        load_coef<R, t>(T, L, t, c);
+    }
+    static __device__ __forceinline__ void fill_unknowns(const Task& T, const LaneOffs& L, Slots<R>& c) {
+        Unroll<R, t - 1, DPP>::fill_unknowns(T, L, c);
+        load_unknowns<R, t>(T, L, t, c);
     }
 };
 template <int R, bool DPP>
 struct Unroll<R, -1, DPP> {
     static __device__ __forceinline__ void run(const ExactArgs&, const Task&, const LaneOffs&, double, int, Slots<R>&,
                                                State&) {}
-    static __device__ __forceinline__ void fill(const Task&, const LaneOffs&, Slots<R>&) {}
+    static __device__ __forceinline__ void fill_coef(const Task&, const LaneOffs&, Slots<R>&) {}
+    static __device__ __forceinline__ void fill_unknowns(const Task&, const LaneOffs&, Slots<R>&) {}
 };
 
 // steps t0 .. t1-1 of the unrolled iteration
@@ -375,6 +388,8 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     // Every load must be covered by the producers' published progress before it is issued.  Iteration i issues the
     // loads of steps < (i + 2) R; its coverage check uses a poll that was itself issued one iteration earlier
     // (consuming a poll forces an in-order vmcnt wait on every older load, so finer-grained polling stalls).
+    // The coefficient operands depend on nobody: their first R steps are requested before the task waits.
+    Unroll<R, R - 1, DPP>::fill_coef(T, L, c);
     Polls pl = poll(D);
     if (!wait_covered(A, pl, D, 2 * R)) return;
     {  // centre of the first cells = the right-old of "step -1" (position 0: zero; lane 0: position 63 above)
@@ -383,7 +398,7 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
         S.duC = c0.x;
         S.dvC = c0.y;
     }
-    Unroll<R, R - 1, DPP>::fill(T, L, c);
+    Unroll<R, R - 1, DPP>::fill_unknowns(T, L, c);
 
     // MARKER loads: a 4-byte load issued right after the store of some step retires (vmcnt is in order) only after
     // that store has completed, so consuming it a few steps later proves the step complete and lets the task

@@ -1,0 +1,98 @@
+"""Parity of the callers' side of the path, through the C ABI, on the GPU:
+
+* uint8 frames: the device-side `/ 255.` must give the bits of the caller's `im.astype(float) / 255.`
+  (Code/Serial/OpticalFlowCalculation.py:65-70), i.e. results identical to the fp64 entry point and to the oracle;
+* sequence mode: pushing frames n, n+1, n+2 (TestSuite.py:69-81 walks overlapping pairs) must return, pair by pair,
+  exactly what independent coarse2fine_flow calls return.
+"""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from papteam_opticalflow_amd import Papof
+    g = Papof(0)
+    yield g
+    g.close()
+
+
+def _frames(res, n=3):
+    return [cases.load_frame_u8(res, i + 1) for i in range(n)]
+
+
+def _f64(u8):
+    return u8.astype(np.float64) / 255.0
+
+
+@pytest.mark.parametrize("res,levels", [("240", 3), ("480", 5)])
+def test_u8_entry_point_is_bit_identical_to_f64_and_oracle(gpu, oracle, res, levels):
+    a8, b8 = _frames(res, 2)
+    got = gpu.coarse2fine_flow_u8(a8, b8, levels)
+    ref = gpu.coarse2fine_flow(_f64(a8), _f64(b8), levels)
+    want = oracle.coarse2fine_flow(_f64(a8), _f64(b8), levels)
+    for name, g, r, w in zip(("vx", "vy", "warpI2"), got, ref, want):
+        assert np.array_equal(g, r), name + ": uint8 path differs from the fp64 path"
+        assert np.abs(g - w).max() <= 1e-9, name
+        print("u8 %s L%d %-7s %s" % (res, levels, name, "(bit-exact vs oracle)" if np.array_equal(g, w) else ""))
+
+
+def test_u8_every_sample_value(gpu):
+    """All 256 sample values go through the device-side division: warp of identical frames returns the frame."""
+    ramp = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    im = np.ascontiguousarray(np.stack([ramp, ramp.T, ramp[::-1]], axis=2))
+    vx, vy, wi, _ = gpu.coarse2fine_flow_u8(im, im, 1)
+    assert not vx.any() and not vy.any()
+    assert np.array_equal(wi, _f64(im))
+
+
+@pytest.mark.parametrize("res,levels,as_u8", [("240", 5, False), ("240", 3, True), ("480", 5, True)])
+def test_sequence_equals_independent_pairs(gpu, res, levels, as_u8):
+    frames = _frames(res, 3)
+    pairs = [gpu.coarse2fine_flow(_f64(frames[i]), _f64(frames[i + 1]), levels)[:3] for i in range(2)]
+    gpu.seq_reset()
+    feed = frames if as_u8 else [_f64(f) for f in frames]
+    assert gpu.seq_push(feed[0], levels) is None  # primes the sequence
+    for i in (1, 2):
+        out = gpu.seq_push(feed[i], levels)
+        assert out is not None
+        for name, g, w in zip(("vx", "vy", "warpI2"), out[:3], pairs[i - 1]):
+            assert np.array_equal(g, w), "pair %d %s" % (i, name)
+        assert out[3][9] > 0
+    # a frame of another shape starts a new sequence instead of failing; so does an intervening ordinary call
+    small = np.ascontiguousarray(feed[0][:64, :80])
+    assert gpu.seq_push(small, 2) is None
+    assert gpu.seq_push(np.ascontiguousarray(feed[1][:64, :80]), 2) is not None
+    gpu.coarse2fine_flow(_f64(frames[0])[:32, :32].copy(), _f64(frames[1])[:32, :32].copy(), 1)
+    assert gpu.seq_push(np.ascontiguousarray(feed[2][:64, :80]), 2) is None
+
+
+def test_sequence_other_levels_or_params_restart_or_continue(gpu):
+    from papteam_opticalflow_amd import default_params
+    f = [_f64(x) for x in _frames("240", 3)]
+    gpu.seq_reset()
+    assert gpu.seq_push(f[0], 3) is None
+    assert gpu.seq_push(f[1], 4) is None          # another pyramid plan: new sequence primed with f[1]
+    p = default_params(n_outer=2, n_outer_per_level=0, n_sor=5, n_sor_per_level=0)
+    out = gpu.seq_push(f[2], 4, p)                # solver parameters may change between pushes
+    want = gpu.coarse2fine_flow(f[1], f[2], 4, p)
+    assert out is not None
+    for g, w in zip(out[:3], want[:3]):
+        assert np.array_equal(g, w)
+
+
+def test_package_level_sequence_and_u8_api():
+    from papteam_opticalflow_amd import FlowSequence, coarse2fine_flow, coarse2fine_flow_u8
+    frames = _frames("240", 3)
+    seq = FlowSequence(2)
+    assert seq.push(frames[0]) is None
+    t, vx, vy, w = seq.push(frames[1])
+    t2, vx2, vy2, w2 = coarse2fine_flow_u8(frames[0], frames[1], 2)
+    t3, vx3, vy3, w3 = coarse2fine_flow(_f64(frames[0]), _f64(frames[1]), 2)
+    assert list(t) == list(t2) == list(t3) and all(isinstance(x, str) for x in t.values())
+    assert np.array_equal(vx, vx2) and np.array_equal(vx, vx3) and np.array_equal(w, w3) and np.array_equal(vy, vy2)
+    seq.close()
