@@ -142,6 +142,7 @@ struct papof_handle {
     int host_threads = 4;            // threads used to move pageable user buffers to / from the pinned buffers
     bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
     int sor_depth = 10;              // software-pipeline depth R (steps) of the exact-order SOR kernel
+    bool sor_xcd_affine = true;      // all sweeps of a band on one XCD (block index -> task mapping, speed only)
     // sequence mode (papof_seq_*): the pyramid of the last pushed frame stays in the arena and becomes "frame 1" of
     // the next pair.  Valid only while the arena block, the frame shape and the pyramid plan stay the same.
     struct Seq {

@@ -74,6 +74,7 @@ struct ExactArgs {
     unsigned* prog;   // [n_sor][nb]
     unsigned* abort;  // one word
     int H, W, nb, ns, hp, npos, qt, rt, npos_d, n_sor;
+    int xcd_affine;
     double nalpha, om1;
 };
 
@@ -341,8 +342,20 @@ template <int R, bool DPP>
 __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     static_assert(R >= 8 && R % 2 == 0, "two markers per iteration, each consumed 3 steps later");
     const unsigned lane = threadIdx.x;
-    const int task = blockIdx.x;
-    const int k = task / A.nb, b = task - k * A.nb;
+    // Workgroups are dealt round-robin over the 8 XCDs (blocks x and x + 8 share one; observed, speed only), so with
+    // xcd_affine the sweeps of one band all run on one XCD: sweep k+1 re-reads the coefficient cells sweep k read a
+    // few dozen steps earlier out of that XCD's L2 instead of the Infinity Cache.  Dependencies still point to lower
+    // block indices only.
+    int k, b;
+    if (A.xcd_affine) {
+        const int x = blockIdx.x & 7, y = blockIdx.x >> 3, nb8 = (A.nb + 7) >> 3;
+        k = y / nb8;
+        b = (y - k * nb8) * 8 + x;
+        if (b >= A.nb) return;
+    } else {
+        k = blockIdx.x / A.nb;
+        b = blockIdx.x - k * A.nb;
+    }
     const int ns = A.ns;
     const bool ghost = lane == 0 || lane == kLanes - 1;
     Task T;
@@ -548,7 +561,10 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.om1 = om1;
         // du = dv = 0 before the first sweep (src/OpticalFlow.cpp:452-453); also clears the ghost-lane mirrors
         PAPOF_HIP(hipMemsetAsync(sp.du, 0, sd.nd * 16, h->stream));  // both parities
-        const dim3 grid(sd.nb * n_sor), block(kLanes);
+        // measured: with at most one band per XCD the affinity is worth 3-4 % (small pyramid levels); beyond that the
+        // uneven band count per XCD costs more than the L2 hits give (1920x1080: 18 bands over 8 XCDs, -5 %)
+        A.xcd_affine = (h->sor_xcd_affine && sd.nb <= 8) ? 1 : 0;
+        const dim3 grid(A.xcd_affine ? 8 * ((sd.nb + 7) / 8) * n_sor : sd.nb * n_sor), block(kLanes);
         const int R = h->sor_depth;
         if (!h->use_dpp)
             hipLaunchKernelGGL((k_sor_exact<8, false>), grid, block, 0, h->stream, A);
