@@ -79,6 +79,90 @@ def cpu_baseline(a, b, levels, sched, mode):
     return kind, dt
 
 
+def measure_tiles(args, gpu, dist, rank, world, d1, d2, h, w, c, sched, dvx, dvy, dwp):
+    """Secondary figure for N>1 (never `value`): ONE frame pair sharded as rows x cols tiles over all ranks, red-black
+    SOR with ghost-zone halo exchange over RCCL (csrc/tiles.hip; BASELINE.json configs[4]) -- strong scaling of a
+    single pair, next to the same red-black solve on one GPU.  A watchdog abandons a stuck collective: every rank
+    leaves after --tiles-timeout seconds and rank 0 reports the timeout instead of a number."""
+    import threading
+
+    import torch
+    from papteam_opticalflow_amd import capi, default_params
+    state = {"phase": "init", "done": False}
+
+    def on_timeout():
+        if not state["done"]:
+            state["timed_out"] = True
+    result = {"sor_mode": "redblack", "scaling": "strong", "halo_halfsweeps": args.tile_halo}
+    timer = threading.Timer(args.tiles_timeout, on_timeout)
+    timer.daemon = True
+    box = {}
+
+    def work():
+        try:
+            rows, cols = capi.tiles_grid(world)
+            result["grid"] = "%dx%d" % (rows, cols)
+            P = default_params(n_outer=sched[0], n_outer_per_level=sched[1], n_sor=sched[2], n_sor_per_level=sched[3],
+                               sor_mode=1, omega=1.8, phase_timing=0)
+            idt = torch.zeros(capi.TILES_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(capi.tiles_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            uid = bytes(idt.cpu().numpy().tobytes())
+            state["phase"] = "comm_init"
+            tr = capi.TileRank.create(gpu, uid, rank, world, rows, cols, args.tile_halo)
+            outs = (dvx, dvy, dwp) if rank == 0 else (None, None, None)
+            state["phase"] = "warmup"
+            tr.flow_device(d1, d2, h, w, c, args.levels, P, *outs)
+            torch.cuda.synchronize()
+            dist.barrier()
+            state["phase"] = "timed"
+            t0 = time.perf_counter()
+            sor = 0.0
+            for _ in range(args.steps):
+                sor += tr.flow_device(d1, d2, h, w, c, args.levels, P, *outs)[6]
+            torch.cuda.synchronize()
+            dist.barrier()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            sec = float(dt.item()) / args.steps
+            n_ex, n_bytes = tr.stats()
+            result.update({"ms_per_pair": round(sec * 1e3, 4), "value": round(h * w / 1e6 / sec, 4), "unit": "Mpix/s",
+                           "sor_ms_per_pair_rank0": round(sor / args.steps * 1e3, 4),
+                           "exchanges_per_pair": n_ex, "exchanged_mb_per_pair_rank0": round(n_bytes / 1e6, 3)})
+            if rank == 0:  # the same solve on one GPU: time, and the tiled result must be bit-identical to it
+                tx, ty = np.zeros((h, w)), np.zeros((h, w))
+                gpu.dev_download(tx, dvx)
+                gpu.dev_download(ty, dvy)
+                gpu.flow_device(d1, d2, h, w, c, args.levels, P, dvx, dvy, dwp)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    gpu.flow_device(d1, d2, h, w, c, args.levels, P, dvx, dvy, dwp)
+                result["one_gpu_redblack_ms_per_pair"] = round((time.perf_counter() - t1) / 3 * 1e3, 4)
+                sx, sy = np.zeros((h, w)), np.zeros((h, w))
+                gpu.dev_download(sx, dvx)
+                gpu.dev_download(sy, dvy)
+                result["bit_identical_to_one_gpu_redblack"] = bool(np.array_equal(tx, sx) and np.array_equal(ty, sy))
+            dist.barrier()
+            tr.close()
+        except Exception as e:  # noqa: BLE001 -- reported, never silently replaced by another path
+            box["error"] = "%s: %s" % (type(e).__name__, e)
+        state["done"] = True
+
+    th = threading.Thread(target=work, daemon=True)
+    timer.start()
+    th.start()
+    while th.is_alive() and not state.get("timed_out"):
+        th.join(0.2)
+    timer.cancel()
+    if state.get("timed_out") and not state["done"]:
+        result["error"] = "timeout after %.0f s in phase %s" % (args.tiles_timeout, state["phase"])
+        result["abandoned"] = True
+    elif "error" in box:
+        result["error"] = box["error"]
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +178,11 @@ def main():
                     help="frame pairs solved concurrently per GPU (one handle + stream + host thread each); a step "
                          "is then one solve of EVERY pair and value counts all of them")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1")
+    ap.add_argument("--no-tiles", action="store_true",
+                    help="N>1: skip the secondary measurement of ONE pair sharded as 2-D tiles over all ranks")
+    ap.add_argument("--tile-halo", type=int, default=10, help="ghost-zone depth of the tiled solve, in half-sweeps")
+    ap.add_argument("--tiles-timeout", type=float, default=120.0,
+                    help="seconds after which a stuck tiled measurement is abandoned (the JSON line is still printed)")
     ap.add_argument("--simulate-step-ms", type=float, default=0.0,
                     help="CPU-only rehearsal of the N>1 protocol (tests): a step sleeps (rank+1) x this long instead "
                          "of running the GPU path; the printed value is meaningless")
@@ -180,6 +269,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)  # the slowest rank defines the job's time
         elapsed = float(tt.item())
 
+    tiles = None
+    if world > 1 and use_cuda and not args.no_tiles:
+        tiles = measure_tiles(args, gpu, dist, rank, world, d1, d2, h, w, c, sched, dvx, dvy, dwp)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.pairs * (h * w / 1e6) / (elapsed / args.steps)
@@ -229,6 +322,8 @@ def main():
                          "avg_launch_ms": round(sor_step * 1e3 / launches, 4) if launches else None,
                          "sor_ms_per_step": round(sor_step * 1e3, 4)},
         }
+        if tiles is not None:
+            out["tiles"] = tiles
         if world == 1 and args.pairs == 1 and not simulate and not args.no_concurrent:
             # secondary figure (not `value`): the same solve for 4 independent pairs in flight on one GPU -- what a
             # collection of frame pairs (the reference's TestSuite walks 101 per set) gets out of the device
@@ -269,6 +364,9 @@ def main():
                                              "thread (the reference Serial path is single-threaded)" % (w, h, dt),
                                    "host_cpus": os.cpu_count()}
         print(json.dumps(out), flush=True)
+    if tiles is not None and tiles.get("abandoned"):
+        sys.stdout.flush()
+        os._exit(0)  # a collective of the tiled attempt is stuck: no orderly teardown is possible
     if gpu is not None:
         for p in (d1, d2, dvx, dvy, dwp):
             gpu.dev_free(p)

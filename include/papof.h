@@ -139,6 +139,38 @@ int papof_seq_push_device(papof_handle* h, const void* d_frame, int is_u8, int h
                           int pyramid_levels, const papof_params* params, double* d_vx, double* d_vy,
                           double* d_warpI2, double timing_sec[PAPOF_N_TIMERS], int* have_flow);
 
+/* ---- ONE frame pair sharded as 2-D tiles over several GPUs (BASELINE.json configs[4]: 1920x1080
+ * tiled 2x4 across 8 GPUs with RCCL halo exchange over xGMI).  One rank per GPU / process; every rank holds both
+ * frames; rank 0 receives the assembled (vx, vy, warpI2).  Red-black SOR order (PAPOF_SOR_REDBLACK, n_inner = 1): a
+ * red-black half-sweep reads only the other colour's previous values, so the tiled result is bit-identical to
+ * papof_flow_device() in that mode on one GPU.  `halo` = ghost-zone depth in half-sweeps (one (du, dv) exchange per
+ * `halo` half-sweeps; 0 = default 10).  All calls below except _grid/_rect/_halo_message are collective. */
+typedef struct papof_tiles papof_tiles;
+#define PAPOF_TILES_ID_BYTES 128
+/* rows x cols grid for n ranks (8 -> 2 x 4: tiles of 480 x 540 at 1080p, 4 -> 2 x 2, 2 -> 1 x 2) */
+int papof_tiles_grid(int nranks, int* rows, int* cols);
+/* rect = {x0, y0, x1, y1} (half-open) of rank's tile of a width x height plane */
+int papof_tiles_rect(int width, int height, int rows, int cols, int rank, int rect[4]);
+/* the rectangle rank `src` sends to rank `dst` when every rank needs its tile grown by `halo` pixels (empty: x1 <= x0);
+ * pure function of its arguments -- both ends of a message compute it, nothing is negotiated */
+int papof_tiles_halo_message(int width, int height, int rows, int cols, int halo, int src, int dst, int rect[4]);
+/* RCCL transport: rank 0 obtains an id (ncclGetUniqueId) and hands it to every rank by whatever means the launcher
+ * has (bench.py: torch.distributed broadcast); then every rank creates its member of the group on its own handle. */
+int papof_tiles_unique_id(unsigned char id[PAPOF_TILES_ID_BYTES]);
+int papof_tiles_create(papof_handle* h, const unsigned char id[PAPOF_TILES_ID_BYTES], int rank, int nranks, int rows,
+                       int cols, int halo, papof_tiles** out);
+/* LOCAL transport: all `nranks` ranks live in this process (one handle each, e.g. all on one device); messages are
+ * device-to-device copies.  Each out[r] must then be driven by its own host thread.  Same orchestration code as the
+ * RCCL transport; exists so that the tiled path can be parity-tested on a one-GPU box. */
+int papof_tiles_create_local(papof_handle* const* handles, int nranks, int rows, int cols, int halo,
+                             papof_tiles** out /* nranks entries */);
+int papof_tiles_flow_device(papof_tiles* t, const double* d_im1, const double* d_im2, int height, int width, int c,
+                            int pyramid_levels, const papof_params* params /* NULL = reference schedule, red-black */,
+                            double* d_vx, double* d_vy, double* d_warpI2 /* rank 0 only; may be NULL elsewhere */,
+                            double timing_sec[PAPOF_N_TIMERS]);
+int papof_tiles_stats(const papof_tiles* t, long* exchanges, size_t* bytes); /* of the last call, this rank */
+void papof_tiles_destroy(papof_tiles* t);
+
 /* Device memory helpers for callers without a HIP binding (bench.py, ctypes users). */
 int papof_dev_alloc(papof_handle* h, size_t bytes, void** out);
 int papof_dev_free(papof_handle* h, void* p);

@@ -44,7 +44,9 @@ SYMBOLS = [
     "papof_stage_resize_wh", "papof_stage_im2feature", "papof_stage_warpFL", "papof_stage_getDxs",
     "papof_stage_linear_system", "papof_stage_laplacian", "papof_stage_sor", "papof_stage_smoothflow",
     "papof_stage_bicubic_warp", "papof_bench_sor", "papof_flow_u8", "papof_flow_device_u8", "papof_seq_reset",
-    "papof_seq_push", "papof_seq_push_u8", "papof_seq_push_device",
+    "papof_seq_push", "papof_seq_push_u8", "papof_seq_push_device", "papof_tiles_grid", "papof_tiles_rect",
+    "papof_tiles_halo_message", "papof_tiles_unique_id", "papof_tiles_create", "papof_tiles_create_local",
+    "papof_tiles_flow_device", "papof_tiles_stats", "papof_tiles_destroy",
 ]
 
 
@@ -83,6 +85,19 @@ def load():
     L.papof_seq_push_u8.argtypes = [c_void_p, _B, c_int, c_int, c_int, c_int, PP, _D, _D, _D, _D, _I]
     L.papof_seq_push_device.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, PP, c_void_p,
                                         c_void_p, c_void_p, _D, _I]
+    L.papof_tiles_grid.argtypes = [c_int, _I, _I]
+    L.papof_tiles_rect.argtypes = [c_int, c_int, c_int, c_int, c_int, _I]
+    L.papof_tiles_halo_message.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _I]
+    L.papof_tiles_unique_id.argtypes = [ctypes.c_char_p]
+    L.papof_tiles_create.argtypes = [c_void_p, ctypes.c_char_p, c_int, c_int, c_int, c_int, c_int,
+                                     ctypes.POINTER(c_void_p)]
+    L.papof_tiles_create_local.argtypes = [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int,
+                                           ctypes.POINTER(c_void_p)]
+    L.papof_tiles_flow_device.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, PP, c_void_p,
+                                          c_void_p, c_void_p, _D]
+    L.papof_tiles_stats.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_size_t)]
+    L.papof_tiles_destroy.argtypes = [c_void_p]
+    L.papof_tiles_destroy.restype = None
     L.papof_dev_alloc.argtypes = [c_void_p, ctypes.c_size_t, ctypes.POINTER(c_void_p)]
     L.papof_dev_free.argtypes = [c_void_p, c_void_p]
     L.papof_dev_upload.argtypes = [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]
@@ -368,3 +383,128 @@ class Papof:
         ms = c_double(0)
         _chk(self.L.papof_bench_sor(self.h, h, w, n_sor, mode, reps, seed, ctypes.byref(ms)), "papof_bench_sor")
         return ms.value
+
+
+# ---- one frame pair sharded as 2-D tiles over several ranks (include/papof.h, csrc/tiles.hip) ---------------------
+TILES_ID_BYTES = 128
+
+
+def tiles_grid(nranks):
+    r, c = c_int(0), c_int(0)
+    _chk(load().papof_tiles_grid(nranks, ctypes.byref(r), ctypes.byref(c)), "papof_tiles_grid")
+    return r.value, c.value
+
+
+def tiles_rect(width, height, rows, cols, rank):
+    out = (c_int * 4)()
+    _chk(load().papof_tiles_rect(width, height, rows, cols, rank, out), "papof_tiles_rect")
+    return tuple(out)
+
+
+def tiles_halo_message(width, height, rows, cols, halo, src, dst):
+    out = (c_int * 4)()
+    _chk(load().papof_tiles_halo_message(width, height, rows, cols, halo, src, dst, out), "papof_tiles_halo_message")
+    return tuple(out)
+
+
+def tiles_unique_id():
+    buf = ctypes.create_string_buffer(TILES_ID_BYTES)
+    _chk(load().papof_tiles_unique_id(buf), "papof_tiles_unique_id")
+    return buf.raw
+
+
+class TileRank:
+    """One rank of a tile group (RCCL transport: one per process / GPU)."""
+
+    def __init__(self, gpu, t):
+        self.gpu, self.t = gpu, t
+
+    @classmethod
+    def create(cls, gpu, unique_id, rank, nranks, rows=0, cols=0, halo=0):
+        if not rows:
+            rows, cols = tiles_grid(nranks)
+        t = c_void_p()
+        _chk(gpu.L.papof_tiles_create(gpu.h, unique_id, rank, nranks, rows, cols, halo, ctypes.byref(t)),
+             "papof_tiles_create")
+        return cls(gpu, t)
+
+    def flow_device(self, d_im1, d_im2, h, w, c, levels, params, d_vx=None, d_vy=None, d_warp=None):
+        t = np.zeros(N_TIMERS)
+        pp = ctypes.byref(params) if params is not None else None
+        _chk(self.gpu.L.papof_tiles_flow_device(self.t, d_im1, d_im2, h, w, c, levels, pp, d_vx, d_vy, d_warp, _p(t)),
+             "papof_tiles_flow_device")
+        return t
+
+    def stats(self):
+        n, b = ctypes.c_long(0), ctypes.c_size_t(0)
+        _chk(self.gpu.L.papof_tiles_stats(self.t, ctypes.byref(n), ctypes.byref(b)), "papof_tiles_stats")
+        return n.value, b.value
+
+    def close(self):
+        if self.t:
+            self.gpu.L.papof_tiles_destroy(self.t)
+            self.t = c_void_p()
+
+
+class LocalTileGroup:
+    """All ranks of a tile group inside this process (LOCAL transport: device copies instead of RCCL), each driven by
+    its own host thread.  For parity tests of the tiled path on a one-GPU box."""
+
+    def __init__(self, nranks, rows=0, cols=0, halo=0, device=0):
+        if not rows:
+            rows, cols = tiles_grid(nranks)
+        self.n, self.rows, self.cols = nranks, rows, cols
+        self.gpus = [Papof(device) for _ in range(nranks)]
+        hs = (c_void_p * nranks)(*[g.h for g in self.gpus])
+        ts = (c_void_p * nranks)()
+        _chk(self.gpus[0].L.papof_tiles_create_local(hs, nranks, rows, cols, halo, ts), "papof_tiles_create_local")
+        self.ranks = [TileRank(g, c_void_p(t)) for g, t in zip(self.gpus, ts)]
+
+    def coarse2fine_flow(self, im1, im2, levels, params):
+        """Host arrays in / out (HWC float64); every rank gets its own device copy of the frames, as one process per
+        GPU would have."""
+        import threading
+        im1, im2 = _c(im1, 3), _c(im2, 3)
+        h, w, c = im1.shape
+        bufs = []
+        for g in self.gpus:
+            d1, d2 = g.dev_alloc(im1.nbytes), g.dev_alloc(im2.nbytes)
+            g.dev_upload(d1, im1)
+            g.dev_upload(d2, im2)
+            bufs.append((d1, d2))
+        g0 = self.gpus[0]
+        dvx, dvy, dwp = g0.dev_alloc(h * w * 8), g0.dev_alloc(h * w * 8), g0.dev_alloc(im1.nbytes)
+        errs, times = [None] * self.n, [None] * self.n
+
+        def run(r):
+            try:
+                o = (dvx, dvy, dwp) if r == 0 else (None, None, None)
+                times[r] = self.ranks[r].flow_device(bufs[r][0], bufs[r][1], h, w, c, levels, params, *o)
+            except Exception as e:  # noqa: BLE001
+                errs[r] = e
+        th = [threading.Thread(target=run, args=(r,)) for r in range(self.n)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        try:
+            for e in errs:
+                if e is not None:
+                    raise e
+            vx, vy, wi = np.zeros((h, w)), np.zeros((h, w)), np.zeros((h, w, c))
+            g0.dev_download(vx, dvx)
+            g0.dev_download(vy, dvy)
+            g0.dev_download(wi, dwp)
+        finally:
+            for g, (d1, d2) in zip(self.gpus, bufs):
+                g.dev_free(d1)
+                g.dev_free(d2)
+            for p in (dvx, dvy, dwp):
+                g0.dev_free(p)
+        return vx, vy, wi, times[0]
+
+    def close(self):
+        for r in self.ranks:
+            r.close()
+        for g in self.gpus:
+            g.close()

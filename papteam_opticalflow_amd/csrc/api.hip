@@ -15,6 +15,7 @@
 #include <thread>
 
 #include "common.h"
+#include "flow_internal.h"
 
 namespace papof {
 
@@ -28,10 +29,9 @@ void set_last_error(const char* what, hipError_t e, const char* file, int line) 
     g_last_error = buf;
 }
 const char* last_error() { return g_last_error.c_str(); }
+void set_last_error_text(const std::string& text) { g_last_error = text; }
 
-namespace {
-
-double wall() {
+static double wall() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
@@ -70,49 +70,6 @@ int ensure_arena(papof_handle* h, size_t bytes) {
     return PAPOF_OK;
 }
 
-// ---- phase timers (HIP events on the handle's stream) ----
-struct PhaseClock {
-    papof_handle* h;
-    bool on;
-    std::vector<std::pair<int, std::pair<size_t, size_t>>> spans;  // (timer index, (event a, event b))
-    size_t open = 0;
-    int open_idx = -1;
-    int err = PAPOF_OK;
-    size_t new_event() {
-        if (h->events_used == h->events.size()) {
-            hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) {
-                err = PAPOF_EDEVICE;
-                return 0;
-            }
-            h->events.push_back(e);
-        }
-        hipEventRecord(h->events[h->events_used], h->stream);
-        return h->events_used++;
-    }
-    // close the running span (if any) and open a new one attributed to timer `idx` (-1: none)
-    void phase(int idx) {
-        if (!on) return;
-        const size_t e = new_event();
-        if (open_idx >= 0) spans.push_back({open_idx, {open, e}});
-        open = e;
-        open_idx = idx;
-    }
-    void collect(double* t) {  // after the stream has drained
-        if (!on) return;
-        for (auto& s : spans) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, h->events[s.second.first], h->events[s.second.second]) == hipSuccess)
-                t[s.first] += ms * 1e-3;
-        }
-    }
-};
-
-struct Level {
-    int w, h;
-    double *p1, *p2;  // planar pyramid levels of frame 1 / frame 2
-};
-
 int check_params(const papof_params& P, int levels) {
     if (levels < 1) return PAPOF_EINVAL;
     if (P.n_inner < 1) return PAPOF_EINVAL;
@@ -121,13 +78,6 @@ int check_params(const papof_params& P, int levels) {
     if (!(P.alpha > 0) || !(P.omega > 0)) return PAPOF_EINVAL;
     return PAPOF_OK;
 }
-
-// GaussianPyramid::ConstructPyramidLevels (src/GaussianPyramid.cpp:79-108) for one frame, planar.
-// levels[i].p (selected by `which`) must be pre-allocated with the dims computed by pyramid_dims().
-struct PyrPlan {
-    int sw, sh, src_level, fsize;
-    double sigma, rate;
-};
 
 int pyramid_plan(int H, int W, double ratio, int nlev, std::vector<Level>& L, std::vector<PyrPlan>& plan) {
     if (ratio > 0.98 || ratio < 0.4) ratio = 0.75;  // :82-83
@@ -228,8 +178,6 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
 }
 
 int feature_channels(int C) { return C == 3 ? 5 : (C == 1 ? 3 : C); }
-
-}  // namespace
 
 // An interleaved HWC frame resident on the device: fp64 in [0,1] (the reference's buffers) or the decoded uint8
 // samples, which are scaled by 1/255 while they are planarised (OpticalFlowCalculation.py:69-70).

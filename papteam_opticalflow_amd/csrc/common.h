@@ -26,6 +26,15 @@ namespace papof {
 constexpr int kLanes = 64;     // CDNA wavefront
 constexpr int kMaxFsize = 8;   // Gaussian half-width supported by the filter kernels
 
+// Half-open pixel rectangle [x0, x1) x [y0, y1) in the coordinates of a full plane.  Every per-pixel kernel takes
+// one: the whole plane on one GPU, a tile (plus the halo a stage needs) when a frame is sharded across GPUs (tiles.hip).
+struct Rect {
+    int x0, y0, x1, y1;
+    __host__ __device__ bool empty() const { return x1 <= x0 || y1 <= y0; }
+    __host__ __device__ int w() const { return x1 - x0; }
+    __host__ __device__ int h() const { return y1 - y0; }
+};
+
 struct Taps {                  // 1-D correlation taps, passed by value as a kernel argument
     double t[2 * kMaxFsize + 1];
     int fsize;
@@ -159,24 +168,29 @@ namespace papof {
 int hwc_to_planar(papof_handle* h, const double* hwc, double* planar, int H, int W, int C);
 int hwc_u8_to_planar(papof_handle* h, const unsigned char* hwc, double* planar, int H, int W, int C);
 int planar_to_hwc(papof_handle* h, const double* planar, double* hwc, int H, int W, int C);
-int filter_h(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f);
-int filter_v(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f);
+int filter_h(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f,
+             const Rect* rc = nullptr);
+int filter_v(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f,
+             const Rect* rc = nullptr);
 int resize(papof_handle* h, const double* src, double* dst, int sh, int sw, int planes, int dh, int dw, double xr,
-           double yr, bool use_post, double post);
+           double yr, bool use_post, double post, const Rect* rc = nullptr);
 int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C);
 int warp_bilinear(papof_handle* h, const double* im1, const double* im2, const double* vx, const double* vy,
-                  double* out, int H, int W, int planes);
+                  double* out, int H, int W, int planes, const Rect* rc = nullptr);
 int smooth_v_blend(papof_handle* h, const double* tmp, const double* im1s, double* blend, double* imdt, int H,
-                   int W, int planes);
-int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlanes* prev, double* phi, int H, int W);
+                   int W, int planes, const Rect* rc = nullptr);
+int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlanes* prev, double* phi, int H, int W,
+                const Rect* rc = nullptr);
 int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,
                     const double* v, int H, int W, int planes, double alpha, double omega, const SorPlanes& out,
-                    double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev);
+                    double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev, const Rect* rc = nullptr);
 int laplacian(papof_handle* h, const double* in, const double* weight, double* out, int H, int W);
 int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, const double* im1,
                     const double* im2, double* warp, int H, int W, int planes);
 int bicubic_warp(papof_handle* h, const double* im1, const double* im2, const double* gx, const double* gy,
-                 const double* gxy, const double* vx, const double* vy, double* out_hwc, int H, int W, int C);
+                 const double* gxy, const double* vx, const double* vy, double* out_hwc, int H, int W, int C,
+                 const Rect* rc = nullptr);
+int update_flow(papof_handle* h, const SorPlanes& sp, double* u, double* v, int H, int W, const Rect& r);
 int sor_prep(papof_handle* h, const double* phi, const double* imdxy, const double* imdx2, const double* imdy2,
              const double* rhs1, const double* rhs2, int H, int W, double alpha, double omega, const SorPlanes& out);
 int sor_unpack(papof_handle* h, const SorPlanes& sp, double* du, double* dv, int H, int W);
@@ -187,6 +201,8 @@ Taps central3_taps();
 
 // ---- sor.hip ----
 int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor, int mode);
+int sor_redblack_halfsweep(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int colour,
+                           const Rect& r);
 int sor_check(papof_handle* h);  // after a stream sync: PAPOF_ETIMEOUT if a device-side wait expired
 int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes& sp);  // carve the operand planes
 int sor_bind(SorPlanes& sp, int H, int W, int n_sor);          // choose the layout of the next solves (skew mode)

@@ -17,6 +17,8 @@ namespace {
 constexpr int BX = 64, BY = 4;
 
 inline dim3 grid2d(int W, int H, int planes = 1) { return dim3((W + BX - 1) / BX, (H + BY - 1) / BY, planes); }
+inline Rect region(const Rect* rc, int W, int H) { return rc ? *rc : Rect{0, 0, W, H}; }
+inline dim3 grid2d(const Rect& r, int planes = 1) { return grid2d(r.x1 - r.x0, r.y1 - r.y0, planes); }
 
 __device__ __forceinline__ int clampi(int x, int n) {  // EnforceRange, src/ImageProcessing.h:34
     x = x < 0 ? 0 : x;
@@ -54,9 +56,9 @@ __global__ void k_planar_to_hwc(const double* __restrict__ planar, double* __res
 // separable correlation with clamped borders: src/ImageProcessing.h:259-279 (h), :350-369 (v).
 // Accumulation into a zeroed destination, taps in order l = -fsize..fsize.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_filter_h(const double* __restrict__ src, double* __restrict__ dst, int H, int W, Taps f) {
-    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
-    if (j >= W || i >= H) return;
+__global__ void k_filter_h(const double* __restrict__ src, double* __restrict__ dst, int H, int W, Taps f, Rect rc) {
+    const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
+    if (j >= rc.x1 || i >= rc.y1) return;
     const size_t np = (size_t)H * W;
     const double* row = src + blockIdx.z * np + (size_t)i * W;
     double acc = 0.0;
@@ -64,9 +66,9 @@ __global__ void k_filter_h(const double* __restrict__ src, double* __restrict__ 
     dst[blockIdx.z * np + (size_t)i * W + j] = acc;
 }
 
-__global__ void k_filter_v(const double* __restrict__ src, double* __restrict__ dst, int H, int W, Taps f) {
-    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
-    if (j >= W || i >= H) return;
+__global__ void k_filter_v(const double* __restrict__ src, double* __restrict__ dst, int H, int W, Taps f, Rect rc) {
+    const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
+    if (j >= rc.x1 || i >= rc.y1) return;
     const size_t np = (size_t)H * W;
     const double* p = src + blockIdx.z * np + j;
     double acc = 0.0;
@@ -114,9 +116,9 @@ __device__ __forceinline__ double bilinear_apply(const double* __restrict__ p, c
 // Optional post-scale = Image::Multiplywith (src/Image.h:1841-1850) for the flow up-sampling of
 // src/OpticalFlow.cpp:809-812.
 __global__ void k_resize(const double* __restrict__ src, double* __restrict__ dst, int sh, int sw, int dh, int dw,
-                         double xr, double yr, int use_post, double post) {
-    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
-    if (j >= dw || i >= dh) return;
+                         double xr, double yr, int use_post, double post, Rect rc) {
+    const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
+    if (j >= rc.x1 || i >= rc.y1) return;
     const double x = (double)(j + 1) / xr - 1;
     const double y = (double)(i + 1) / yr - 1;
     const BilinearTaps b = bilinear_taps(sw, sh, x, y);
@@ -174,9 +176,9 @@ __device__ __forceinline__ void warp_pixel(const double* __restrict__ im1, const
 }
 
 __global__ void k_warp(const double* __restrict__ im1, const double* __restrict__ im2, const double* __restrict__ vx,
-                       const double* __restrict__ vy, double* __restrict__ out, int H, int W, int planes) {
-    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
-    if (j >= W || i >= H) return;
+                       const double* __restrict__ vy, double* __restrict__ out, int H, int W, int planes, Rect rc) {
+    const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
+    if (j >= rc.x1 || i >= rc.y1) return;
     const size_t o = (size_t)i * W + j;
     warp_pixel(im1, im2, out, vx[o], vy[o], i, j, H, W, planes);
 }
@@ -187,9 +189,9 @@ __global__ void k_warp(const double* __restrict__ im1, const double* __restrict_
 // imdt = Im2s - Im1s (:97).  Im1s (smoothed frame 1) is constant within a level and computed once.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_smooth_v_blend(const double* __restrict__ tmp, const double* __restrict__ im1s,
-                                 double* __restrict__ blend, double* __restrict__ imdt, int H, int W, Taps g) {
-    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
-    if (j >= W || i >= H) return;
+                                 double* __restrict__ blend, double* __restrict__ imdt, int H, int W, Taps g, Rect rc) {
+    const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
+    if (j >= rc.x1 || i >= rc.y1) return;
     const size_t np = (size_t)H * W, o = blockIdx.z * np + (size_t)i * W + j;
     const double* p = tmp + blockIdx.z * np + j;
     double s2 = 0.0;
@@ -252,9 +254,9 @@ __device__ __forceinline__ void increment_at(const Increment& I, int i, int j, i
 // (zero in the last column / row, src/Image.h:979-986, :1022-1029), phi = 0.5/sqrt(ux^2+uy^2+vx^2+vy^2+eps).
 // ------------------------------------------------------------------------------------------------
 __global__ void k_phi(const double* __restrict__ u, const double* __restrict__ v, Increment I,
-                      double* __restrict__ phi, int H, int W) {
-    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
-    if (j >= W || i >= H) return;
+                      double* __restrict__ phi, int H, int W, Rect rc) {
+    const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
+    if (j >= rc.x1 || i >= rc.y1) return;
     const size_t o = (size_t)i * W + j;
     double uc = u[o], vc = v[o], ur = 0.0, vr = 0.0, ud = 0.0, vd = 0.0;
     if (j < W - 1) {
@@ -405,9 +407,9 @@ __global__ void k_assemble(const double* __restrict__ blend, const double* __res
                            const double* __restrict__ v, int H, int W, int planes, double alpha, double omega,
                            double* __restrict__ o_phi, double* __restrict__ o_xy, double* __restrict__ o_a1,
                            double* __restrict__ o_a2, double* __restrict__ o_b1, double* __restrict__ o_b2,
-                           double* __restrict__ o_x2, double* __restrict__ o_y2, Taps d, Increment I) {
-    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
-    if (j >= W || i >= H) return;
+                           double* __restrict__ o_x2, double* __restrict__ o_y2, Taps d, Increment I, Rect rc) {
+    const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
+    if (j >= rc.x1 || i >= rc.y1) return;
     const size_t o = (size_t)i * W + j;
     const SystemCell c = assemble_cell(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I);
     o_phi[o] = c.phi;
@@ -513,16 +515,17 @@ __global__ void k_sor_unpack(const double* __restrict__ sdu, const double* __res
 // ------------------------------------------------------------------------------------------------
 __global__ void k_update_warp(const double* __restrict__ sdu, const double* __restrict__ sdv, double* __restrict__ u,
                               double* __restrict__ v, const double* __restrict__ im1,
-                              const double* __restrict__ im2, double* __restrict__ warp, int H, int W, int planes) {
-    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
-    if (j >= W || i >= H) return;
+                              const double* __restrict__ im2, double* __restrict__ warp, int H, int W, int planes, Rect rc,
+                              int do_warp) {
+    const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
+    if (j >= rc.x1 || i >= rc.y1) return;
     const size_t o = (size_t)i * W + j;
     double fu = u[o], fv = v[o];
     fu += sdu[o];
     fv += sdv[o];
     u[o] = fu;
     v[o] = fv;
-    warp_pixel(im1, im2, warp, fu, fv, i, j, H, W, planes);
+    if (do_warp) warp_pixel(im1, im2, warp, fu, fv, i, j, H, W, planes);
 }
 
 // Exact-order solver layout: (du, dv) read straight from the paired skewed plane (16 bytes per thread; an LDS-staged
@@ -552,9 +555,9 @@ __global__ void k_update_warp_skew(const double2s* __restrict__ pd, double* __re
 __global__ void k_bicubic(const double* __restrict__ im1, const double* __restrict__ im2,
                           const double* __restrict__ gx, const double* __restrict__ gy,
                           const double* __restrict__ gxy, const double* __restrict__ vx,
-                          const double* __restrict__ vy, double* __restrict__ out, int H, int W, int C) {
-    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
-    if (j >= W || i >= H) return;
+                          const double* __restrict__ vy, double* __restrict__ out, int H, int W, int C, Rect rc) {
+    const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
+    if (j >= rc.x1 || i >= rc.y1) return;
     const size_t np = (size_t)H * W, o = (size_t)i * W + j;
     const double x = j + vx[o];
     const double y = i + vy[o];
@@ -678,22 +681,28 @@ int planar_to_hwc(papof_handle* h, const double* planar, double* hwc, int H, int
     return PAPOF_OK;
 }
 
-int filter_h(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f) {
-    hipLaunchKernelGGL(k_filter_h, grid2d(W, H, planes), dim3(BX, BY), 0, h->stream, src, dst, H, W, f);
+int filter_h(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f, const Rect* rc) {
+    const Rect r = region(rc, W, H);
+    if (r.empty()) return PAPOF_OK;
+    hipLaunchKernelGGL(k_filter_h, grid2d(r, planes), dim3(BX, BY), 0, h->stream, src, dst, H, W, f, r);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
 
-int filter_v(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f) {
-    hipLaunchKernelGGL(k_filter_v, grid2d(W, H, planes), dim3(BX, BY), 0, h->stream, src, dst, H, W, f);
+int filter_v(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f, const Rect* rc) {
+    const Rect r = region(rc, W, H);
+    if (r.empty()) return PAPOF_OK;
+    hipLaunchKernelGGL(k_filter_v, grid2d(r, planes), dim3(BX, BY), 0, h->stream, src, dst, H, W, f, r);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
 
 int resize(papof_handle* h, const double* src, double* dst, int sh, int sw, int planes, int dh, int dw, double xr,
-           double yr, bool use_post, double post) {
-    hipLaunchKernelGGL(k_resize, grid2d(dw, dh, planes), dim3(BX, BY), 0, h->stream, src, dst, sh, sw, dh, dw, xr,
-                       yr, use_post ? 1 : 0, post);
+           double yr, bool use_post, double post, const Rect* rc) {
+    const Rect r = region(rc, dw, dh);
+    if (r.empty()) return PAPOF_OK;
+    hipLaunchKernelGGL(k_resize, grid2d(r, planes), dim3(BX, BY), 0, h->stream, src, dst, sh, sw, dh, dw, xr, yr,
+                       use_post ? 1 : 0, post, r);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
@@ -712,16 +721,20 @@ int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, in
 }
 
 int warp_bilinear(papof_handle* h, const double* im1, const double* im2, const double* vx, const double* vy,
-                  double* out, int H, int W, int planes) {
-    hipLaunchKernelGGL(k_warp, grid2d(W, H), dim3(BX, BY), 0, h->stream, im1, im2, vx, vy, out, H, W, planes);
+                  double* out, int H, int W, int planes, const Rect* rc) {
+    const Rect r = region(rc, W, H);
+    if (r.empty()) return PAPOF_OK;
+    hipLaunchKernelGGL(k_warp, grid2d(r), dim3(BX, BY), 0, h->stream, im1, im2, vx, vy, out, H, W, planes, r);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
 
 int smooth_v_blend(papof_handle* h, const double* tmp, const double* im1s, double* blend, double* imdt, int H,
-                   int W, int planes) {
-    hipLaunchKernelGGL(k_smooth_v_blend, grid2d(W, H, planes), dim3(BX, BY), 0, h->stream, tmp, im1s, blend, imdt,
-                       H, W, smooth5_taps());
+                   int W, int planes, const Rect* rc) {
+    const Rect r = region(rc, W, H);
+    if (r.empty()) return PAPOF_OK;
+    hipLaunchKernelGGL(k_smooth_v_blend, grid2d(r, planes), dim3(BX, BY), 0, h->stream, tmp, im1s, blend, imdt, H, W,
+                       smooth5_taps(), r);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
@@ -736,25 +749,31 @@ static Increment increment_of(const SorPlanes* prev) {
     return Increment{prev->du, prev->dv, prev->skew ? 1 : 0, prev->skew ? skew_idx(*prev) : SkewIdx{0, 0, 0, 0, 0, 0}};
 }
 
-int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlanes* prev, double* phi, int H, int W) {
-    hipLaunchKernelGGL(k_phi, grid2d(W, H), dim3(BX, BY), 0, h->stream, u, v, increment_of(prev), phi, H, W);
+int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlanes* prev, double* phi, int H, int W,
+                const Rect* rc) {
+    const Rect r = region(rc, W, H);
+    if (r.empty()) return PAPOF_OK;
+    hipLaunchKernelGGL(k_phi, grid2d(r), dim3(BX, BY), 0, h->stream, u, v, increment_of(prev), phi, H, W, r);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
 
 int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,
                     const double* v, int H, int W, int planes, double alpha, double omega, const SorPlanes& out,
-                    double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev) {
+                    double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev, const Rect* rc) {
     const Increment I = increment_of(prev);
+    const Rect r = region(rc, W, H);
+    if (r.empty()) return PAPOF_OK;
     if (out.skew) {
+        if (rc) return PAPOF_EINVAL;  // regions exist for the row-major (tile) path only
         hipLaunchKernelGGL(k_assemble_skew, dim3((W + kTileJ - 1) / kTileJ, (H + kBandRows - 1) / kBandRows),
                            dim3(256), 0, h->stream, blend, imdt, phi, u, v, H, W, planes, alpha, omega, skew_idx(out),
                            (double2s*)out.phi, (double2s*)out.a1, (double2s*)out.b1, opt_imdx2, opt_imdy2,
                            deriv5_taps(), I);
     } else {
-        hipLaunchKernelGGL(k_assemble, grid2d(W, H), dim3(BX, BY), 0, h->stream, blend, imdt, phi, u, v, H, W, planes,
+        hipLaunchKernelGGL(k_assemble, grid2d(r), dim3(BX, BY), 0, h->stream, blend, imdt, phi, u, v, H, W, planes,
                            alpha, omega, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2, opt_imdx2, opt_imdy2,
-                           deriv5_taps(), I);
+                           deriv5_taps(), I, r);
     }
     LAUNCH_CHECK();
     return PAPOF_OK;
@@ -773,16 +792,29 @@ int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, 
                            im1, im2, warp, H, W, planes, skew_idx(sp));
     } else {
         hipLaunchKernelGGL(k_update_warp, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, u, v, im1, im2, warp,
-                           H, W, planes);
+                           H, W, planes, Rect{0, 0, W, H}, 1);
     }
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
 
+// tile path: u += du, v += dv on a region, no warp (the warp follows the halo exchange of u, v)
+int update_flow(papof_handle* h, const SorPlanes& sp, double* u, double* v, int H, int W, const Rect& r) {
+    if (sp.skew) return PAPOF_EINVAL;
+    if (r.empty()) return PAPOF_OK;
+    hipLaunchKernelGGL(k_update_warp, grid2d(r), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, u, v, nullptr, nullptr, nullptr,
+                       H, W, 0, r, 0);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
 int bicubic_warp(papof_handle* h, const double* im1, const double* im2, const double* gx, const double* gy,
-                 const double* gxy, const double* vx, const double* vy, double* out_hwc, int H, int W, int C) {
-    hipLaunchKernelGGL(k_bicubic, grid2d(W, H), dim3(BX, BY), 0, h->stream, im1, im2, gx, gy, gxy, vx, vy, out_hwc,
-                       H, W, C);
+                 const double* gxy, const double* vx, const double* vy, double* out_hwc, int H, int W, int C,
+                 const Rect* rc) {
+    const Rect r = region(rc, W, H);
+    if (r.empty()) return PAPOF_OK;
+    hipLaunchKernelGGL(k_bicubic, grid2d(r), dim3(BX, BY), 0, h->stream, im1, im2, gx, gy, gxy, vx, vy, out_hwc, H, W,
+                       C, r);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }

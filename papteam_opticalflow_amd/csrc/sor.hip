@@ -490,11 +490,12 @@ __device__ __forceinline__ void cell_update(const double* __restrict__ phi, cons
 __global__ void k_sor_redblack(const double* __restrict__ phi, const double* __restrict__ xy,
                                const double* __restrict__ a1, const double* __restrict__ a2,
                                const double* __restrict__ b1, const double* __restrict__ b2, double* du, double* dv,
-                               int H, int W, double nalpha, double om1, int colour) {
-    const int i = blockIdx.y * 4 + threadIdx.y;
-    if (i >= H) return;
-    const int j = 2 * (blockIdx.x * 64 + threadIdx.x) + ((i + colour) & 1);
-    if (j >= W) return;
+                               int H, int W, double nalpha, double om1, int colour, Rect rc) {
+    const int i = rc.y0 + blockIdx.y * 4 + threadIdx.y;
+    if (i >= rc.y1) return;
+    // cells with (i + j) % 2 == colour; the class of a cell does not depend on the region it is visited in
+    const int j = rc.x0 + 2 * (blockIdx.x * 64 + threadIdx.x) + ((i + rc.x0 + colour) & 1);
+    if (j >= rc.x1) return;
     cell_update(phi, xy, a1, a2, b1, b2, du, dv, du, dv, i, j, H, W, nalpha, om1);
 }
 
@@ -509,6 +510,19 @@ __global__ void k_sor_jacobi(const double* __restrict__ phi, const double* __res
 }
 
 }  // namespace
+
+// One colour of a red-black sweep on a region of the (row-major) operand planes.  The whole plane on one GPU; a tile
+// grown by its remaining ghost depth when a frame is sharded (tiles.hip).
+int sor_redblack_halfsweep(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int colour,
+                           const Rect& r) {
+    if (sp.skew) return PAPOF_EINVAL;
+    if (r.empty()) return PAPOF_OK;
+    const dim3 grid(((r.w() + 1) / 2 + 63) / 64, (r.h() + 3) / 4), block(64, 4);
+    hipLaunchKernelGGL(k_sor_redblack, grid, block, 0, h->stream, sp.phi, sp.xy, sp.a1, sp.a2, sp.b1, sp.b2, sp.du,
+                       sp.dv, H, W, -alpha, 1 - omega, colour, r);
+    PAPOF_HIP(hipGetLastError());
+    return PAPOF_OK;
+}
 
 int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor, int mode) {
     const double nalpha = -alpha, om1 = 1 - omega;
@@ -582,12 +596,9 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
     PAPOF_HIP(hipMemsetAsync(sp.du, 0, np * sizeof(double), h->stream));  // src/OpticalFlow.cpp:452-453
     PAPOF_HIP(hipMemsetAsync(sp.dv, 0, np * sizeof(double), h->stream));
     if (mode == PAPOF_SOR_REDBLACK) {
-        const dim3 grid(((W + 1) / 2 + 63) / 64, (H + 3) / 4), block(64, 4);
         for (int k = 0; k < n_sor; k++)
             for (int colour = 0; colour < 2; colour++)
-                hipLaunchKernelGGL(k_sor_redblack, grid, block, 0, h->stream, sp.phi, sp.xy, sp.a1, sp.a2, sp.b1,
-                                   sp.b2, sp.du, sp.dv, H, W, nalpha, om1, colour);
-        PAPOF_HIP(hipGetLastError());
+                PAPOF_TRY(sor_redblack_halfsweep(h, sp, H, W, alpha, omega, colour, Rect{0, 0, W, H}));
         return PAPOF_OK;
     }
     if (mode == PAPOF_SOR_JACOBI) {

@@ -1,0 +1,670 @@
+// papteam_opticalflow_amd/csrc/tiles.hip -- ONE frame pair sharded as 2-D tiles over several GPUs (SURVEY.md §8e,
+// BASELINE.json configs[4]: "1920x1080 tiled 2x4 across 8 x MI355X, RCCL halo exchange over xGMI each SOR sweep").
+//
+// Same pipeline as flow_device() (api.hip; reference: OpticalFlow::Coarse2FineFlow, src/OpticalFlow.cpp:735-903) with
+// the red-black SOR order (sor.hip), one rank per GPU:
+//   * every rank keeps FULL-SIZE planes in global pixel coordinates and launches each per-pixel kernel on a region
+//     (Rect): its tile grown by exactly the halo the following stages read.  Cheap read-only inputs are replicated
+//     instead of exchanged: both pyramids and the per-level features are built redundantly on every rank (the warp is an
+//     unbounded gather of frame-2 features, so they have to be resident everywhere anyway).
+//   * what IS exchanged, owner -> needer, packed into one buffer per peer and moved by one RCCL group
+//     (ncclSend / ncclRecv on the rank's own stream: no host round trip, no collective that involves non-neighbours):
+//       - (du, dv) during a solve.  Ghost zones are S half-sweeps deep: after an exchange (du, dv) are valid on the tile
+//         grown by S; half-sweep m of a block then runs on the tile grown by S-1-m (redundant work on a shrinking
+//         frame), so one exchange serves S half-sweeps.  Xgmi messages of a few KB are latency-bound, so S trades ~S/2
+//         extra pixel rings of arithmetic for 1/S of the exchanges.  Red-black half-sweeps read only the other colour's
+//         previous values, hence the tiled result is BIT-IDENTICAL to the one-GPU red-black solve (tested).
+//       - (u, v) after each outer iteration: a halo of S+3 pixels (warp S+3 -> 5-tap smoothing, both passes S+1 ->
+//         5-point derivatives / phi / Laplacian S -> coefficients on S-1 -> ghost-zone solve);
+//       - (u, v) at a level change: the rectangle the bilinear up-sampling of the next level's grown tile reads;
+//       - the finished tiles of (u, v, warpI2) to rank 0.
+//   * message plans are pure functions of (dims, grid, rank): both ends compute them, nothing is negotiated.
+//
+// Transports: RCCL (production; librccl is dlopen'ed so that a one-GPU user never needs it, and so that a process
+// that already loaded PyTorch's copy shares it) and LOCAL (all ranks are threads of one process on one device and
+// messages are device-to-device copies): the same orchestration code, used by the parity tests on a one-GPU box.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is loaded at run time
+
+#include "common.h"
+#include "flow_internal.h"
+
+namespace papof {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// geometry (host)
+// ---------------------------------------------------------------------------------------------------------
+struct TileGrid {
+    int rows, cols;
+    int n() const { return rows * cols; }
+};
+
+Rect tile_rect(const TileGrid& g, int rank, int W, int H) {
+    const int ty = rank / g.cols, tx = rank - ty * g.cols;
+    return Rect{(int)((long long)W * tx / g.cols), (int)((long long)H * ty / g.rows),
+                (int)((long long)W * (tx + 1) / g.cols), (int)((long long)H * (ty + 1) / g.rows)};
+}
+
+Rect grow(const Rect& r, int d, int W, int H) {  // clamped to the image; an empty tile stays empty
+    if (r.empty()) return r;
+    return Rect{std::max(0, r.x0 - d), std::max(0, r.y0 - d), std::min(W, r.x1 + d), std::min(H, r.y1 + d)};
+}
+
+Rect intersect(const Rect& a, const Rect& b) {
+    Rect r{std::max(a.x0, b.x0), std::max(a.y0, b.y0), std::min(a.x1, b.x1), std::min(a.y1, b.y1)};
+    if (r.empty()) r = Rect{0, 0, 0, 0};
+    return r;
+}
+
+// Source rectangle (in the sw x sh plane) that ResizeImage's bilinear sampler (src/ImageProcessing.h:235-253,
+// :138-157) reads for the destination pixels of `dst`: x = (j+1)/xr - 1, taps at (int)x and (int)x + 1, clamped.
+// One pixel of slack on both sides covers the rounding of the division.
+Rect resize_source(const Rect& dst, double xr, double yr, int sw, int sh) {
+    if (dst.empty()) return Rect{0, 0, 0, 0};
+    const int x0 = (int)std::floor((double)(dst.x0 + 1) / xr - 1) - 1, x1 = (int)std::floor((double)dst.x1 / xr - 1) + 3;
+    const int y0 = (int)std::floor((double)(dst.y0 + 1) / yr - 1) - 1, y1 = (int)std::floor((double)dst.y1 / yr - 1) + 3;
+    return Rect{std::max(0, x0), std::max(0, y0), std::min(sw, x1), std::min(sh, y1)};
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// transports
+// ---------------------------------------------------------------------------------------------------------
+struct Msg {
+    int peer;
+    double* buf;
+    size_t count;  // doubles
+};
+
+struct Transport {
+    int rank = 0, nranks = 1;
+    virtual ~Transport() {}
+    // Everything enqueued on h->stream before the call is visible to the sends; everything enqueued after it sees the
+    // received data.
+    virtual int exchange(papof_handle* h, const std::vector<Msg>& sends, const std::vector<Msg>& recvs) = 0;
+};
+
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+const RcclApi* rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // the soname first: a process that already holds a librccl (PyTorch's) gets that very copy back
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void* lib = nullptr;
+        for (const char* n : names)
+            if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!lib) return;
+        RcclApi a;
+        a.lib = lib;
+#define PAPOF_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(lib, name))
+        PAPOF_SYM(GetUniqueId, "ncclGetUniqueId");
+        PAPOF_SYM(CommInitRank, "ncclCommInitRank");
+        PAPOF_SYM(CommDestroy, "ncclCommDestroy");
+        PAPOF_SYM(GroupStart, "ncclGroupStart");
+        PAPOF_SYM(GroupEnd, "ncclGroupEnd");
+        PAPOF_SYM(Send, "ncclSend");
+        PAPOF_SYM(Recv, "ncclRecv");
+        PAPOF_SYM(GetErrorString, "ncclGetErrorString");
+#undef PAPOF_SYM
+        if (a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv &&
+            a.GetErrorString)
+            api = a;
+    });
+    return api.lib ? &api : nullptr;
+}
+
+#define PAPOF_NCCL(api, expr)                                                                    \
+    do {                                                                                         \
+        ncclResult_t _r = (expr);                                                                \
+        if (_r != ncclSuccess) {                                                                 \
+            set_last_error_text(std::string(#expr " failed: ") + (api)->GetErrorString(_r));     \
+            return PAPOF_EDEVICE;                                                                \
+        }                                                                                        \
+    } while (0)
+
+struct RcclTransport : Transport {
+    const RcclApi* api = nullptr;
+    ncclComm_t comm = nullptr;
+    ~RcclTransport() override {
+        if (comm) api->CommDestroy(comm);
+    }
+    int exchange(papof_handle* h, const std::vector<Msg>& sends, const std::vector<Msg>& recvs) override {
+        if (sends.empty() && recvs.empty()) return PAPOF_OK;
+        PAPOF_NCCL(api, api->GroupStart());
+        for (const Msg& m : sends) PAPOF_NCCL(api, api->Send(m.buf, m.count, ncclDouble, m.peer, comm, h->stream));
+        for (const Msg& m : recvs) PAPOF_NCCL(api, api->Recv(m.buf, m.count, ncclDouble, m.peer, comm, h->stream));
+        PAPOF_NCCL(api, api->GroupEnd());
+        return PAPOF_OK;
+    }
+};
+
+// All ranks are threads of one process (tests on a one-GPU box): a send is posted in a shared table, the receiver copies
+// device-to-device.  Two barriers per exchange (posted / consumed); a rank that fails releases the others with an error.
+struct LocalGroup {
+    int n;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    long generation = 0;
+    bool failed = false;
+    std::vector<std::vector<Msg>> posted;
+    explicit LocalGroup(int n_) : n(n_), posted(n_) {}
+    bool barrier() {  // false: the group has failed (a rank bailed out, or a rank never arrived)
+        std::unique_lock<std::mutex> lk(mu);
+        if (failed) return false;
+        const long gen = generation;
+        if (++arrived == n) {
+            arrived = 0;
+            generation++;
+            cv.notify_all();
+            return true;
+        }
+        if (!cv.wait_for(lk, std::chrono::seconds(30), [&] { return generation != gen || failed; })) failed = true;
+        if (failed) cv.notify_all();
+        return !failed;
+    }
+    void fail() {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        cv.notify_all();
+    }
+};
+
+struct LocalTransport : Transport {
+    std::shared_ptr<LocalGroup> g;
+    int exchange(papof_handle* h, const std::vector<Msg>& sends, const std::vector<Msg>& recvs) override {
+        if (hipStreamSynchronize(h->stream) != hipSuccess) {
+            g->fail();
+            return PAPOF_EDEVICE;
+        }
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->posted[rank] = sends;
+        }
+        if (!g->barrier()) return PAPOF_ETIMEOUT;
+        int rc = PAPOF_OK;
+        for (const Msg& m : recvs) {
+            const Msg* src = nullptr;
+            for (const Msg& s : g->posted[m.peer])
+                if (s.peer == rank) src = &s;
+            if (!src || src->count != m.count) {  // the two ends disagree about the plan
+                rc = PAPOF_EINVAL;
+                break;
+            }
+            if (hipMemcpyAsync(m.buf, src->buf, m.count * sizeof(double), hipMemcpyDeviceToDevice, h->stream) !=
+                hipSuccess)
+                rc = PAPOF_EDEVICE;
+        }
+        if (rc == PAPOF_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = PAPOF_EDEVICE;
+        if (rc != PAPOF_OK) {
+            g->fail();
+            return rc;
+        }
+        if (!g->barrier()) return PAPOF_ETIMEOUT;  // nobody repacks its send buffer before every reader is done
+        return PAPOF_OK;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// owner -> needer exchange of rectangles of full-size planes
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMaxMsgs = 24, kMaxPlanes = 2;
+struct MsgTable {
+    int n, nplanes, W;
+    size_t plane_stride;
+    double* planes[kMaxPlanes];
+    Rect r[kMaxMsgs];
+    unsigned long long off[kMaxMsgs];  // doubles from the start of the staging buffer
+};
+
+template <bool PACK>
+__global__ void k_rects(MsgTable t, double* __restrict__ buf) {
+    const int m = blockIdx.z / t.nplanes, p = blockIdx.z - m * t.nplanes;
+    const Rect r = t.r[m];
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= r.w() || y >= r.h()) return;
+    double* cell = t.planes[p] + (size_t)(r.y0 + y) * t.W + (r.x0 + x);
+    double* slot = buf + t.off[m] + ((size_t)p * r.h() + y) * r.w() + x;
+    if (PACK)
+        *slot = *cell;
+    else
+        *cell = *slot;
+}
+
+}  // namespace
+
+}  // namespace papof
+
+using namespace papof;
+
+struct papof_tiles {
+    papof_handle* h = nullptr;
+    TileGrid grid{1, 1};
+    int halo = 10;  // S: ghost-zone depth in half-sweeps
+    std::unique_ptr<Transport> tp;
+    double *send_stage = nullptr, *recv_stage = nullptr;
+    size_t stage_cap = 0;  // doubles, each
+    long exchanges = 0;    // statistics of the last call
+    size_t exchanged_bytes = 0;
+    ~papof_tiles() {
+        if (h) hipSetDevice(h->device);
+        if (send_stage) hipFree(send_stage);
+        if (recv_stage) hipFree(recv_stage);
+    }
+};
+
+namespace papof {
+namespace {
+
+int ensure_stage(papof_tiles& t, size_t doubles) {
+    if (doubles <= t.stage_cap) return PAPOF_OK;
+    PAPOF_HIP(hipStreamSynchronize(t.h->stream));
+    if (t.send_stage) PAPOF_HIP(hipFree(t.send_stage));
+    if (t.recv_stage) PAPOF_HIP(hipFree(t.recv_stage));
+    t.send_stage = t.recv_stage = nullptr;
+    t.stage_cap = 0;
+    const size_t cap = doubles + doubles / 4 + 4096;
+    if (hipMalloc((void**)&t.send_stage, cap * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&t.recv_stage, cap * sizeof(double)) != hipSuccess) {
+        set_last_error_text("hipMalloc(tile exchange staging) failed");
+        return PAPOF_ENOMEM;
+    }
+    t.stage_cap = cap;
+    return PAPOF_OK;
+}
+
+using RectOf = std::function<Rect(int)>;
+
+// Every rank r OWNS own(r) (disjoint) and NEEDS need(r) of the given planes (row length W, `plane_stride` doubles
+// apart... each plane is its own pointer).  After the call need(me) is valid on this rank.
+int exchange_planes(papof_tiles& t, double* const* planes, int nplanes, int W, const RectOf& own, const RectOf& need) {
+    const int me = t.tp->rank, n = t.tp->nranks;
+    if (n == 1) return PAPOF_OK;
+    if (nplanes > kMaxPlanes) return PAPOF_EINVAL;
+    MsgTable st{}, rt{};
+    st.nplanes = rt.nplanes = nplanes;
+    st.W = rt.W = W;
+    for (int p = 0; p < nplanes; p++) st.planes[p] = rt.planes[p] = planes[p];
+    std::vector<Msg> sends, recvs;
+    size_t soff = 0, roff = 0;
+    const Rect mine = own(me), want = need(me);
+    for (int r = 0; r < n; r++) {
+        if (r == me) continue;
+        const Rect out = intersect(mine, need(r)), in = intersect(own(r), want);
+        if (!out.empty()) {
+            if (st.n == kMaxMsgs) return PAPOF_EINVAL;
+            st.r[st.n] = out;
+            st.off[st.n++] = soff;
+            const size_t c = (size_t)out.w() * out.h() * nplanes;
+            sends.push_back(Msg{r, nullptr, c});
+            soff += c;
+        }
+        if (!in.empty()) {
+            if (rt.n == kMaxMsgs) return PAPOF_EINVAL;
+            rt.r[rt.n] = in;
+            rt.off[rt.n++] = roff;
+            const size_t c = (size_t)in.w() * in.h() * nplanes;
+            recvs.push_back(Msg{r, nullptr, c});
+            roff += c;
+        }
+    }
+    PAPOF_TRY(ensure_stage(t, std::max(soff, roff)));
+    for (size_t i = 0; i < sends.size(); i++) sends[i].buf = t.send_stage + st.off[i];
+    for (size_t i = 0; i < recvs.size(); i++) recvs[i].buf = t.recv_stage + rt.off[i];
+    const auto launch_dims = [](const MsgTable& m) {
+        int mw = 1, mh = 1;
+        for (int i = 0; i < m.n; i++) {
+            mw = std::max(mw, m.r[i].w());
+            mh = std::max(mh, m.r[i].h());
+        }
+        return dim3((mw + 63) / 64, (mh + 3) / 4, m.n * m.nplanes);
+    };
+    hipStream_t s = t.h->stream;
+    if (st.n) hipLaunchKernelGGL(k_rects<true>, launch_dims(st), dim3(64, 4), 0, s, st, t.send_stage);
+    PAPOF_HIP(hipGetLastError());
+    PAPOF_TRY(t.tp->exchange(t.h, sends, recvs));
+    if (rt.n) hipLaunchKernelGGL(k_rects<false>, launch_dims(rt), dim3(64, 4), 0, s, rt, t.recv_stage);
+    PAPOF_HIP(hipGetLastError());
+    t.exchanges++;
+    t.exchanged_bytes += (soff + roff) * sizeof(double);
+    return PAPOF_OK;
+}
+
+// The call, from one rank's point of view.  Collective: every rank of the group calls it with the same arguments
+// (each with its own device-resident copy of the two frames); rank 0 receives the assembled results.
+int tiles_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, int W, int C, int levels,
+               const papof_params& P, double* d_vx, double* d_vy, double* d_warp, double* timing) {
+    papof_handle* h = t.h;
+    PAPOF_TRY(check_params(P, levels));
+    if (P.sor_mode != PAPOF_SOR_REDBLACK || P.n_inner != 1) {
+        set_last_error_text("tiled solves use the red-black sweep order (sor_mode = PAPOF_SOR_REDBLACK) with n_inner = 1");
+        return PAPOF_EINVAL;
+    }
+    double ratio = P.ratio;
+    if (ratio > 0.98 || ratio < 0.4) ratio = 0.75;
+    std::vector<Level> L;
+    std::vector<PyrPlan> plan;
+    PAPOF_TRY(pyramid_plan(H, W, P.ratio, levels, L, plan));
+    const int n_sor_max = P.n_sor + (levels - 1) * P.n_sor_per_level;
+    h->seq.valid = false;
+    PAPOF_TRY(ensure_arena(h, arena_bytes_for(H, W, C, levels, n_sor_max) + (size_t)H * W * C * sizeof(double)));
+    Arena& A = h->arena;
+    A.off = 0;
+    A.overflow = false;
+    h->events_used = 0;
+    t.exchanges = 0;
+    t.exchanged_bytes = 0;
+    const size_t np0 = (size_t)H * W;
+    const int fc = feature_channels(C);
+    const int me = t.tp->rank, S = t.halo, HU = S + 3;
+    double tm[PAPOF_N_TIMERS];
+    std::memset(tm, 0, sizeof tm);
+    PhaseClock total{h, true}, sorclk{h, true};
+    total.phase(PAPOF_T_TOTAL);
+
+    // replicated, read-only: both pyramids (GaussianPyramid::ConstructPyramidLevels, src/GaussianPyramid.cpp:79-108)
+    for (int i = 0; i < levels; i++) {
+        L[i].p1 = A.f64((size_t)L[i].w * L[i].h * C);
+        L[i].p2 = A.f64((size_t)L[i].w * L[i].h * C);
+    }
+    double* tmp_a = A.f64(np0 * C);
+    double* tmp_b = A.f64(np0 * C);
+    if (A.overflow) return PAPOF_ENOMEM;
+    PAPOF_TRY(hwc_to_planar(h, d_im1, L[0].p1, H, W, C));
+    PAPOF_TRY(hwc_to_planar(h, d_im2, L[0].p2, H, W, C));
+    PAPOF_TRY(build_pyramid(h, L, plan, C, false, tmp_a, tmp_b));
+    PAPOF_TRY(build_pyramid(h, L, plan, C, true, tmp_a, tmp_b));
+
+    double* f1 = A.f64(np0 * fc);
+    double* f2 = A.f64(np0 * fc);
+    double* warp = A.f64(np0 * fc);
+    double* u = A.f64(np0);
+    double* v = A.f64(np0);
+    double* u2 = A.f64(np0);
+    double* v2 = A.f64(np0);
+    double* im1s = A.f64(np0 * fc);
+    double* tmp = A.f64(np0 * fc);
+    double* blend = A.f64(np0 * fc);
+    double* imdt = A.f64(np0 * fc);
+    double* phi = A.f64(np0);
+    double* warp_hwc = A.f64(np0 * C);  // this rank's tile of warpI2, in place in a full-size interleaved image
+    SorPlanes sp{};
+    PAPOF_TRY(sor_alloc_planes(A, H, W, PAPOF_SOR_REDBLACK, n_sor_max, sp));
+    if (A.overflow) return PAPOF_ENOMEM;
+    // the solver reads the weights of the LEFT and UPPER neighbours too: one ring beyond the cells it updates, i.e.
+    // beyond the region the assembly wrote its copy of phi for -- so it gets the phi plane itself (valid one ring wider)
+    SorPlanes spt = sp;
+    spt.phi = phi;
+    const Taps g = smooth5_taps();
+
+    int pw = 0, ph = 0;
+    for (int k = levels - 1; k >= 0; k--) {
+        const int lw = L[k].w, lh = L[k].h;
+        const size_t np = (size_t)lw * lh;
+        const RectOf own = [&](int r) { return tile_rect(t.grid, r, lw, lh); };
+        const Rect T = own(me);
+        const Rect Tu = grow(T, HU, lw, lh);  // where this rank keeps (u, v) and the warped features valid
+        PAPOF_TRY(im2feature(h, L[k].p1, f1, lh, lw, C));  // replicated (src/OpticalFlow.cpp:797-798)
+        PAPOF_TRY(im2feature(h, L[k].p2, f2, lh, lw, C));
+        if (k == levels - 1) {  // :801-806
+            PAPOF_HIP(hipMemsetAsync(u, 0, np * sizeof(double), h->stream));
+            PAPOF_HIP(hipMemsetAsync(v, 0, np * sizeof(double), h->stream));
+            PAPOF_HIP(hipMemcpyAsync(warp, f2, np * fc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        } else {  // :809-814: up-sample the coarser flow onto the grown tile, then warp
+            const double xr = (double)lw / pw, yr = (double)lh / ph, inv = 1 / ratio;
+            const int cw = pw, chh = ph;
+            const RectOf own_c = [&](int r) { return tile_rect(t.grid, r, cw, chh); };
+            const RectOf need_c = [&](int r) {
+                return resize_source(grow(tile_rect(t.grid, r, lw, lh), HU, lw, lh), xr, yr, cw, chh);
+            };
+            double* uv[2] = {u, v};
+            PAPOF_TRY(exchange_planes(t, uv, 2, cw, own_c, need_c));
+            PAPOF_TRY(resize(h, u, u2, ph, pw, 1, lh, lw, xr, yr, true, inv, &Tu));
+            PAPOF_TRY(resize(h, v, v2, ph, pw, 1, lh, lw, xr, yr, true, inv, &Tu));
+            std::swap(u, u2);
+            std::swap(v, v2);
+            PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc, &Tu));
+        }
+        // OpticalFlow::SmoothFlowSOR (src/OpticalFlow.cpp:238-536) on the tile
+        const int n_outer = P.n_outer + k * P.n_outer_per_level, n_sor = P.n_sor + k * P.n_sor_per_level;
+        const Rect Rim = grow(T, S + 1, lw, lh);                    // smoothed / blended features
+        const Rect Rh{Rim.x0, Tu.y0, Rim.x1, Tu.y1};                // horizontal pass: two more rows for the vertical one
+        const Rect Rphi = grow(T, S, lw, lh), Rsys = grow(T, S - 1, lw, lh);
+        const RectOf need_d = [&](int r) { return grow(tile_rect(t.grid, r, lw, lh), S, lw, lh); };
+        const RectOf need_u = [&](int r) { return grow(tile_rect(t.grid, r, lw, lh), HU, lw, lh); };
+        PAPOF_TRY(filter_h(h, f1, tmp, lh, lw, fc, g, &Rh));
+        PAPOF_TRY(filter_v(h, tmp, im1s, lh, lw, fc, g, &Rim));
+        for (int count = 0; count < n_outer; count++) {
+            PAPOF_TRY(filter_h(h, warp, tmp, lh, lw, fc, g, &Rh));
+            PAPOF_TRY(smooth_v_blend(h, tmp, im1s, blend, imdt, lh, lw, fc, &Rim));
+            PAPOF_TRY(compute_phi(h, u, v, nullptr, phi, lh, lw, &Rphi));
+            PAPOF_TRY(assemble_system(h, blend, imdt, phi, u, v, lh, lw, fc, P.alpha, P.omega, sp, nullptr, nullptr,
+                                      nullptr, &Rsys));
+            sorclk.phase(PAPOF_T_PHASE5_SOR);
+            PAPOF_HIP(hipMemsetAsync(sp.du, 0, np * sizeof(double), h->stream));  // src/OpticalFlow.cpp:452-453
+            PAPOF_HIP(hipMemsetAsync(sp.dv, 0, np * sizeof(double), h->stream));
+            double* dd[2] = {sp.du, sp.dv};
+            const int n_half = 2 * n_sor;
+            for (int hs = 0; hs < n_half; hs++) {
+                const int m = hs % S;
+                const Rect R = grow(T, S - 1 - m, lw, lh);
+                PAPOF_TRY(sor_redblack_halfsweep(h, spt, lh, lw, P.alpha, P.omega, hs & 1, R));
+                if (m == S - 1 && hs != n_half - 1) PAPOF_TRY(exchange_planes(t, dd, 2, lw, own, need_d));
+            }
+            sorclk.phase(-1);
+            PAPOF_TRY(update_flow(h, sp, u, v, lh, lw, T));  // :513-514
+            double* uv[2] = {u, v};
+            PAPOF_TRY(exchange_planes(t, uv, 2, lw, own, need_u));
+            PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc, &Tu));  // :516
+        }
+        pw = lw;
+        ph = lh;
+    }
+
+    // src/OpticalFlow.cpp:841-842: bicubic warp of the ORIGINAL frame 2 on the tile, then everything to rank 0
+    {
+        double* gx = A.f64(np0 * C);
+        double* gy = A.f64(np0 * C);
+        double* gxy = A.f64(np0 * C);
+        if (A.overflow) return PAPOF_ENOMEM;
+        const Taps c3 = central3_taps();
+        PAPOF_TRY(filter_h(h, L[0].p2, gx, H, W, C, c3));
+        PAPOF_TRY(filter_v(h, L[0].p2, gy, H, W, C, c3));
+        PAPOF_TRY(filter_v(h, gx, gxy, H, W, C, c3));
+        const Rect T = tile_rect(t.grid, me, W, H);
+        PAPOF_TRY(bicubic_warp(h, L[0].p1, L[0].p2, gx, gy, gxy, u, v, warp_hwc, H, W, C, &T));
+        const RectOf own = [&](int r) { return tile_rect(t.grid, r, W, H); };
+        const RectOf need = [&](int r) { return r == 0 ? Rect{0, 0, W, H} : Rect{0, 0, 0, 0}; };
+        double* uv[2] = {u, v};
+        PAPOF_TRY(exchange_planes(t, uv, 2, W, own, need));
+        const RectOf own_c = [&](int r) {
+            const Rect q = tile_rect(t.grid, r, W, H);
+            return Rect{q.x0 * C, q.y0, q.x1 * C, q.y1};
+        };
+        const RectOf need_c = [&](int r) { return r == 0 ? Rect{0, 0, W * C, H} : Rect{0, 0, 0, 0}; };
+        double* wp[1] = {warp_hwc};
+        PAPOF_TRY(exchange_planes(t, wp, 1, W * C, own_c, need_c));
+        if (me == 0) {
+            if (!d_vx || !d_vy || !d_warp) return PAPOF_EINVAL;
+            PAPOF_HIP(hipMemcpyAsync(d_vx, u, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            PAPOF_HIP(hipMemcpyAsync(d_vy, v, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            PAPOF_HIP(hipMemcpyAsync(d_warp, warp_hwc, np0 * C * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
+    total.phase(-1);
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    if (total.err != PAPOF_OK || sorclk.err != PAPOF_OK) return PAPOF_EDEVICE;
+    sorclk.collect(tm);
+    total.collect(tm);
+    if (timing) std::memcpy(timing, tm, sizeof tm);
+    return PAPOF_OK;
+}
+
+}  // namespace
+}  // namespace papof
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int papof_tiles_grid(int nranks, int* rows, int* cols) {
+    if (nranks < 1 || !rows || !cols) return PAPOF_EINVAL;
+    // widest-first split: 8 -> 2 x 4 (tiles of 480 x 540 at 1920 x 1080, the shorter perimeter: SURVEY.md §8e),
+    // 4 -> 2 x 2, 2 -> 1 x 2; any other count: the most square factorisation with cols >= rows
+    int r = (int)std::sqrt((double)nranks);
+    while (r > 1 && nranks % r) r--;
+    *rows = r;
+    *cols = nranks / r;
+    return PAPOF_OK;
+}
+
+int papof_tiles_rect(int width, int height, int rows, int cols, int rank, int rect[4]) {
+    if (width < 1 || height < 1 || rows < 1 || cols < 1 || rank < 0 || rank >= rows * cols || !rect) return PAPOF_EINVAL;
+    const Rect r = tile_rect(TileGrid{rows, cols}, rank, width, height);
+    rect[0] = r.x0;
+    rect[1] = r.y0;
+    rect[2] = r.x1;
+    rect[3] = r.y1;
+    return PAPOF_OK;
+}
+
+int papof_tiles_halo_message(int width, int height, int rows, int cols, int halo, int src, int dst, int rect[4]) {
+    if (width < 1 || height < 1 || rows < 1 || cols < 1 || halo < 0 || !rect) return PAPOF_EINVAL;
+    const int n = rows * cols;
+    if (src < 0 || src >= n || dst < 0 || dst >= n) return PAPOF_EINVAL;
+    const TileGrid g{rows, cols};
+    Rect r{0, 0, 0, 0};
+    if (src != dst) r = intersect(tile_rect(g, src, width, height), grow(tile_rect(g, dst, width, height), halo, width, height));
+    rect[0] = r.x0;
+    rect[1] = r.y0;
+    rect[2] = r.x1;
+    rect[3] = r.y1;
+    return PAPOF_OK;
+}
+
+int papof_tiles_unique_id(unsigned char id[PAPOF_TILES_ID_BYTES]) {
+    if (!id) return PAPOF_EINVAL;
+    const RcclApi* api = rccl();
+    if (!api) {
+        set_last_error_text("librccl could not be loaded");
+        return PAPOF_ENODEVICE;
+    }
+    static_assert(sizeof(ncclUniqueId) <= PAPOF_TILES_ID_BYTES, "unique id does not fit");
+    ncclUniqueId uid;
+    PAPOF_NCCL(api, api->GetUniqueId(&uid));
+    std::memset(id, 0, PAPOF_TILES_ID_BYTES);
+    std::memcpy(id, &uid, sizeof uid);
+    return PAPOF_OK;
+}
+
+static int tiles_common(papof_handle* h, int nranks, int rows, int cols, int halo, papof_tiles** out) {
+    if (!h || !out || nranks < 1 || rows < 1 || cols < 1 || rows * cols != nranks || halo < 0) return PAPOF_EINVAL;
+    *out = new papof_tiles();
+    (*out)->h = h;
+    (*out)->grid = TileGrid{rows, cols};
+    (*out)->halo = halo == 0 ? 10 : halo;
+    return PAPOF_OK;
+}
+
+int papof_tiles_create(papof_handle* h, const unsigned char id[PAPOF_TILES_ID_BYTES], int rank, int nranks, int rows,
+                       int cols, int halo, papof_tiles** out) {
+    if (!id || rank < 0 || rank >= nranks) return PAPOF_EINVAL;
+    const RcclApi* api = rccl();
+    if (!api) {
+        set_last_error_text("librccl could not be loaded");
+        return PAPOF_ENODEVICE;
+    }
+    PAPOF_TRY(tiles_common(h, nranks, rows, cols, halo, out));
+    PAPOF_HIP(hipSetDevice(h->device));
+    auto tp = std::make_unique<RcclTransport>();
+    tp->api = api;
+    tp->rank = rank;
+    tp->nranks = nranks;
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    ncclResult_t r = api->CommInitRank(&tp->comm, nranks, uid, rank);
+    if (r != ncclSuccess) {
+        set_last_error_text(std::string("ncclCommInitRank failed: ") + api->GetErrorString(r));
+        tp->comm = nullptr;
+        delete *out;
+        *out = nullptr;
+        return PAPOF_EDEVICE;
+    }
+    (*out)->tp = std::move(tp);
+    return PAPOF_OK;
+}
+
+int papof_tiles_create_local(papof_handle* const* handles, int nranks, int rows, int cols, int halo,
+                             papof_tiles** out) {
+    if (!handles || !out || nranks < 1) return PAPOF_EINVAL;
+    auto group = std::make_shared<LocalGroup>(nranks);
+    for (int r = 0; r < nranks; r++) out[r] = nullptr;
+    for (int r = 0; r < nranks; r++) {
+        int rc = tiles_common(handles[r], nranks, rows, cols, halo, &out[r]);
+        if (rc != PAPOF_OK) {
+            for (int q = 0; q < r; q++) {
+                delete out[q];
+                out[q] = nullptr;
+            }
+            return rc;
+        }
+        auto tp = std::make_unique<LocalTransport>();
+        tp->rank = r;
+        tp->nranks = nranks;
+        tp->g = group;
+        out[r]->tp = std::move(tp);
+    }
+    return PAPOF_OK;
+}
+
+int papof_tiles_flow_device(papof_tiles* t, const double* d_im1, const double* d_im2, int height, int width, int c,
+                            int pyramid_levels, const papof_params* params, double* d_vx, double* d_vy,
+                            double* d_warpI2, double timing_sec[PAPOF_N_TIMERS]) {
+    if (!t || !t->h || !t->tp || !d_im1 || !d_im2 || height < 1 || width < 1 || c < 1) return PAPOF_EINVAL;
+    papof_params P;
+    if (params)
+        P = *params;
+    else {
+        papof_default_params(&P);
+        P.sor_mode = PAPOF_SOR_REDBLACK;
+    }
+    PAPOF_HIP(hipSetDevice(t->h->device));
+    int rc = tiles_flow(*t, d_im1, d_im2, height, width, c, pyramid_levels, P, d_vx, d_vy, d_warpI2, timing_sec);
+    if (rc != PAPOF_OK)
+        if (auto* lt = dynamic_cast<LocalTransport*>(t->tp.get())) lt->g->fail();  // release the sibling threads
+    return rc;
+}
+
+int papof_tiles_stats(const papof_tiles* t, long* exchanges, size_t* bytes) {
+    if (!t) return PAPOF_EINVAL;
+    if (exchanges) *exchanges = t->exchanges;
+    if (bytes) *bytes = t->exchanged_bytes;
+    return PAPOF_OK;
+}
+
+void papof_tiles_destroy(papof_tiles* t) { delete t; }
+
+}  // extern "C"

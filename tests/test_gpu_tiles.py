@@ -1,0 +1,115 @@
+"""The tiled multi-GPU path (csrc/tiles.hip; SURVEY.md §8e, BASELINE.json configs[4]) on ONE GPU: all ranks of the tile
+group live in this process (LOCAL transport: device copies in place of the RCCL sends), each driven by its own thread --
+the orchestration, the regions every kernel runs on, the message plans and the ghost-zone schedule are the code the
+RCCL transport runs.  A red-black half-sweep reads only the other colour's previous values, so the tiled solve must be
+BIT-IDENTICAL to the one-GPU red-black solve, which in turn is checked against the oracle run in the same mode."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from papteam_opticalflow_amd import Papof
+    g = Papof(0)
+    yield g
+    g.close()
+
+
+def _params(**kw):
+    from papteam_opticalflow_amd import default_params
+    kw.setdefault("sor_mode", 1)
+    return default_params(**kw)
+
+
+def _run_tiles(nranks, rows, cols, halo, a, b, levels, P):
+    from papteam_opticalflow_amd.capi import LocalTileGroup
+    grp = LocalTileGroup(nranks, rows, cols, halo)
+    try:
+        out = grp.coarse2fine_flow(a, b, levels, P)
+        stats = grp.ranks[0].stats()
+    finally:
+        grp.close()
+    return out, stats
+
+
+@pytest.mark.parametrize("res,levels,rows,cols,halo", [
+    ("240", 3, 1, 2, 4), ("240", 5, 2, 2, 10), ("240", 4, 2, 4, 6), ("240", 3, 3, 1, 1), ("480", 5, 2, 4, 10),
+    ("240", 2, 1, 3, 7),
+])
+def test_tiled_equals_single_gpu_redblack(gpu, res, levels, rows, cols, halo):
+    a, b = cases.load_pair(res)
+    P = _params()
+    want = gpu.coarse2fine_flow(a, b, levels, P)[:3]
+    (vx, vy, wi, t), (n_ex, n_bytes) = _run_tiles(rows * cols, rows, cols, halo, a, b, levels, P)
+    for name, g, w in zip(("vx", "vy", "warpI2"), (vx, vy, wi), want):
+        assert np.array_equal(g, w), "%s differs: max-abs %.3e" % (name, np.abs(g - w).max())
+    assert t[9] > 0 and t[6] > 0 and n_ex > 0 and n_bytes > 0
+    print("tiles %dx%d halo %d on %s L%d: %d exchanges, %.2f MB moved by rank 0" % (rows, cols, halo, res, levels, n_ex,
+                                                                                     n_bytes / 1e6))
+
+
+def test_tiled_ragged_sizes_and_schedule(gpu, oracle):
+    a, b = cases.load_pair("240")
+    a = np.ascontiguousarray(a[:101, :173])
+    b = np.ascontiguousarray(b[:101, :173])
+    kw = dict(n_outer=2, n_outer_per_level=1, n_sor=7, n_sor_per_level=2, alpha=0.02, omega=1.5)
+    P = _params(**kw)
+    (vx, vy, wi, _), _ = _run_tiles(6, 2, 3, 5, a, b, 3, P)
+    want = gpu.coarse2fine_flow(a, b, 3, P)[:3]
+    for g, w in zip((vx, vy, wi), want):
+        assert np.array_equal(g, w)
+    p = oracle.default_params()
+    for k, v in dict(kw, sor_mode=1).items():
+        setattr(p, k, v)
+    ow = oracle.coarse2fine_flow(a, b, 3, p)[:3]
+    for name, g, w in zip(("vx", "vy", "warpI2"), (vx, vy, wi), ow):
+        assert np.abs(g - w).max() <= 1e-9, name
+
+
+def test_tiled_config4_schedule_full_hd_tile_grid(gpu):
+    """BASELINE.json configs[4] geometry (2 x 4 tiles) with the config-4 schedule at 960x540 (full HD is the bench)."""
+    a, b = cases.load_pair("960")
+    P = _params(n_outer=3, n_outer_per_level=0, n_sor=30, n_sor_per_level=0)
+    (vx, vy, wi, _), (n_ex, _) = _run_tiles(8, 2, 4, 10, a, b, 5, P)
+    want = gpu.coarse2fine_flow(a, b, 5, P)[:3]
+    for g, w in zip((vx, vy, wi), want):
+        assert np.array_equal(g, w)
+    assert n_ex == 15 * (5 + 1) + 4 + 2  # per solve: 60 half-sweeps / 10 - 1 exchanges + (u, v); level changes; gather
+
+
+def test_tiled_rejects_exact_order_and_inner_iterations(gpu):
+    from papteam_opticalflow_amd import PapofError
+    a, b = cases.load_pair("240")
+    for kw in (dict(sor_mode=0), dict(n_inner=2)):
+        with pytest.raises(PapofError):
+            _run_tiles(2, 1, 2, 4, a, b, 2, _params(**kw))
+
+
+def test_rccl_transport_loads_and_runs_a_group_of_one(gpu):
+    """The RCCL transport itself (dlopen of librccl, ncclGetUniqueId, ncclCommInitRank) on the one GPU this box has:
+    a group of one rank has no peers, so this covers the library plumbing, not the sends (those need >= 2 GPUs and are
+    exercised by bench.py --gpus N on the multi-GPU node)."""
+    from papteam_opticalflow_amd import capi
+    a, b = cases.load_pair("240")
+    P = _params()
+    uid = capi.tiles_unique_id()
+    assert len(uid) == capi.TILES_ID_BYTES and any(uid)
+    tr = capi.TileRank.create(gpu, uid, 0, 1)
+    h, w, c = a.shape
+    d1, d2 = gpu.dev_alloc(a.nbytes), gpu.dev_alloc(b.nbytes)
+    dx, dy, dw = gpu.dev_alloc(h * w * 8), gpu.dev_alloc(h * w * 8), gpu.dev_alloc(a.nbytes)
+    gpu.dev_upload(d1, a)
+    gpu.dev_upload(d2, b)
+    tr.flow_device(d1, d2, h, w, c, 3, P, dx, dy, dw)
+    vx, wi = np.zeros((h, w)), np.zeros((h, w, c))
+    gpu.dev_download(vx, dx)
+    gpu.dev_download(wi, dw)
+    tr.close()
+    for p in (d1, d2, dx, dy, dw):
+        gpu.dev_free(p)
+    want = gpu.coarse2fine_flow(a, b, 3, P)
+    assert np.array_equal(vx, want[0]) and np.array_equal(wi, want[2])
