@@ -36,9 +36,16 @@ static double wall() {
 }
 
 // generous upper bound of the arena one call needs: every buffer is at most level-0 sized
-size_t arena_bytes_for(int H, int W, int C, int levels, int n_sor_max) {
+size_t arena_bytes_for(int H, int W, int C, int levels, int n_sor_max, double ratio) {
     const size_t np = (size_t)H * W;
     const int fc = (C == 3) ? 5 : (C == 1 ? 3 : C);
+    size_t per_level = 0;  // features of both frames and the smoothed features of frame 1, kept for EVERY level
+    {
+        std::vector<Level> L;
+        std::vector<PyrPlan> plan;
+        if (levels >= 1 && pyramid_plan(H, W, ratio, levels, L, plan) == PAPOF_OK)
+            for (const Level& l : L) per_level += ((size_t)l.w * l.h * fc * sizeof(double) + 256) * 3;
+    }
     const SkewDims sd = skew_dims(H, W, n_sor_max);
     size_t planes = 0;
     planes += (size_t)2 * C * 5;           // two pyramids: sum of ratio^(2i) < 2.3 for ratio<=.75; 5 is safe to .98
@@ -49,6 +56,7 @@ size_t arena_bytes_for(int H, int W, int C, int levels, int n_sor_max) {
     planes += (size_t)3 * C + C;           // bicubic derivative planes + interleaved output
     size_t bytes = planes * np * sizeof(double);
     bytes += 3 * (sd.n + 2 * kLanes) * 16 + (sd.nd + 2 * kLanes) * 16 + 10 * np * sizeof(double);  // SOR operands
+    bytes += per_level + np * fc * sizeof(double);  // + the preparation stream's own filter temporary
     bytes += (size_t)64 * 4096;            // alignment slack
     return bytes;
 }
@@ -147,15 +155,19 @@ int alloc_solve_buffers(Arena& A, int H, int W, int fc, int mode, int n_sor_cap,
 // is never read; the noise estimate only feeds a `< 1e-20` guard) and are not executed.
 int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* warp, double* u, double* v, int H,
                 int W, int fc, double alpha, int n_outer, int n_inner, int n_sor, double omega, int mode,
-                SolveBuffers& B, PhaseClock& clk, PhaseClock& sorclk) {
+                SolveBuffers& B, PhaseClock& clk, PhaseClock& sorclk, const double* im1s_ready = nullptr) {
     const Taps g = smooth5_taps();
     clk.phase(PAPOF_T_PHASE1_GENERATE);
-    PAPOF_TRY(filter_h(h, f1, B.tmp, H, W, fc, g));  // smoothed frame 1: constant within the level
-    PAPOF_TRY(filter_v(h, B.tmp, B.im1s, H, W, fc, g));
+    const double* im1s = im1s_ready;  // smoothed frame 1: constant within the level (prepared ahead by flow_device)
+    if (!im1s) {
+        PAPOF_TRY(filter_h(h, f1, B.tmp, H, W, fc, g));
+        PAPOF_TRY(filter_v(h, B.tmp, B.im1s, H, W, fc, g));
+        im1s = B.im1s;
+    }
     for (int count = 0; count < n_outer; count++) {
         clk.phase(PAPOF_T_PHASE1_GENERATE);
         PAPOF_TRY(filter_h(h, warp, B.tmp, H, W, fc, g));
-        PAPOF_TRY(smooth_v_blend(h, B.tmp, B.im1s, B.blend, B.imdt, H, W, fc));
+        PAPOF_TRY(smooth_v_blend(h, B.tmp, im1s, B.blend, B.imdt, H, W, fc));
         // inner fixed-point iterations (src/OpticalFlow.cpp:290-506): after the first one, phi is taken at u + du and
         // psi at imdt + imdx*du + imdy*dv with the increment of the previous solve; the solve itself restarts at 0
         for (int hh = 0; hh < n_inner; hh++) {
@@ -214,7 +226,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     std::vector<PyrPlan> plan;
     PAPOF_TRY(pyramid_plan(H, W, P.ratio, levels, L, plan));
     const int n_sor_max = P.n_sor + (levels - 1) * P.n_sor_per_level;
-    const size_t need = arena_bytes_for(H, W, C, levels, n_sor_max);
+    const size_t need = arena_bytes_for(H, W, C, levels, n_sor_max, P.ratio);
     if (op == kSeqNext && !seq_matches(h, H, W, C, levels, ratio, need)) {
         g_last_error = "sequence push does not continue the primed sequence (shape, levels, ratio or arena changed)";
         return PAPOF_EINVAL;
@@ -246,10 +258,6 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     double* tmp_a = A.f64(np0 * C);
     double* tmp_b = A.f64(np0 * C);
     if (A.overflow) return PAPOF_ENOMEM;
-    if (op != kSeqNext) {
-        PAPOF_TRY(load_frame(h, fa, L[0].p1, H, W, C));
-        PAPOF_TRY(build_pyramid(h, L, plan, C, false, tmp_a, tmp_b));
-    }
     const auto keep = [&](int slot) {
         h->seq.valid = true;
         h->seq.h = H;
@@ -261,16 +269,30 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         h->seq.arena_base = A.base;
     };
     if (op == kSeqPrime) {
+        PAPOF_TRY(load_frame(h, fa, L[0].p1, H, W, C));
+        PAPOF_TRY(build_pyramid(h, L, plan, C, false, tmp_a, tmp_b));
         PAPOF_HIP(hipStreamSynchronize(h->stream));
         keep(slot1);
         if (timing) std::memset(timing, 0, sizeof tm);
         return PAPOF_OK;
     }
-    PAPOF_TRY(load_frame(h, fb, L[0].p2, H, W, C));
-    PAPOF_TRY(build_pyramid(h, L, plan, C, true, tmp_a, tmp_b));
 
-    double* f1 = A.f64(np0 * fc);
-    double* f2 = A.f64(np0 * fc);
+    // Everything that does not depend on the flow -- the pyramids, and per level the features of both frames
+    // (src/OpticalFlow.cpp:797-798) and the smoothed features of frame 1 (getDxs, :84-90) -- is PREPARED on a second
+    // stream, coarsest level first, while the main stream already solves the coarse levels: their SOR solves are
+    // dependency-latency bound and leave most of the chip idle.  One event per level orders the two streams.  With all
+    // ten reference timers requested the call runs on one stream so that the phases do not overlap.
+    std::vector<double*> F1(levels), F2(levels), S1(levels);
+    for (int k = 0; k < levels; k++) {
+        const size_t n = (size_t)L[k].w * L[k].h * fc;
+        F1[k] = A.f64(n);
+        F2[k] = A.f64(n);
+        S1[k] = A.f64(n);
+    }
+    double* prep_tmp = A.f64(np0 * fc);
+    double* gx = A.f64(np0 * C);  // central differences of frame 2 for the final bicubic warp (src/Image.h:2590-2594)
+    double* gy = A.f64(np0 * C);
+    double* gxy = A.f64(np0 * C);
     double* warp = A.f64(np0 * fc);
     double* u = A.f64(np0);
     double* v = A.f64(np0);
@@ -280,46 +302,111 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     PAPOF_TRY(alloc_solve_buffers(A, H, W, fc, P.sor_mode, n_sor_max, B));
     if (A.overflow) return PAPOF_ENOMEM;
 
-    int pw = 0, ph = 0;
-    for (int k = levels - 1; k >= 0; k--) {
-        clk.phase(PAPOF_T_ALLOCATION);
-        const int lw = L[k].w, lh = L[k].h;
-        const size_t np = (size_t)lw * lh;
-        PAPOF_TRY(im2feature(h, L[k].p1, f1, lh, lw, C));  // src/OpticalFlow.cpp:797-798
-        PAPOF_TRY(im2feature(h, L[k].p2, f2, lh, lw, C));
-        if (k == levels - 1) {  // :801-806
-            PAPOF_HIP(hipMemsetAsync(u, 0, np * sizeof(double), h->stream));
-            PAPOF_HIP(hipMemsetAsync(v, 0, np * sizeof(double), h->stream));
-            PAPOF_HIP(hipMemcpyAsync(warp, f2, np * fc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        } else {  // :809-814
-            const double xr = (double)lw / pw, yr = (double)lh / ph, inv = 1 / ratio;
-            PAPOF_TRY(resize(h, u, u2, ph, pw, 1, lh, lw, xr, yr, true, inv));
-            PAPOF_TRY(resize(h, v, v2, ph, pw, 1, lh, lw, xr, yr, true, inv));
-            std::swap(u, u2);
-            std::swap(v, v2);
-            PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc));
-        }
-        PAPOF_TRY(sor_bind(B.sp, lh, lw, P.n_sor + k * P.n_sor_per_level));
-        PAPOF_TRY(sor_reset_planes(h, B.sp));
-        PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, lh, lw, fc, P.alpha, P.n_outer + k * P.n_outer_per_level,
-                              P.n_inner, P.n_sor + k * P.n_sor_per_level, P.omega, P.sor_mode, B, clk, sorclk));
-        pw = lw;
-        ph = lh;
+    const bool overlap = h->overlap_prep && P.phase_timing == 0 && h->prep_stream != nullptr;
+    hipStream_t const main_stream = h->stream, prep = overlap ? h->prep_stream : h->stream;
+    while (h->sync_events.size() < (size_t)levels + 2) {
+        hipEvent_t e;
+        PAPOF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->sync_events.push_back(e);
     }
-
-    clk.phase(PAPOF_T_POSTPROCESSING);  // src/OpticalFlow.cpp:841-842
-    {
-        double* gx = A.f64(np0 * C);
-        double* gy = A.f64(np0 * C);
-        double* gxy = A.f64(np0 * C);
-        if (A.overflow) return PAPOF_ENOMEM;
+    struct StreamSwap {  // the launch wrappers enqueue on h->stream
+        papof_handle* h;
+        hipStream_t saved;
+        StreamSwap(papof_handle* hh, hipStream_t s) : h(hh), saved(hh->stream) { h->stream = s; }
+        ~StreamSwap() { h->stream = saved; }
+    };
+    const auto prepare = [&]() -> int {
+        StreamSwap on_prep(h, prep);
+        if (op != kSeqNext) PAPOF_TRY(load_frame(h, fa, L[0].p1, H, W, C));
+        PAPOF_TRY(load_frame(h, fb, L[0].p2, H, W, C));
+        // pyramid levels coarsest first when every level is derived from level 0 (<= 5 levels at ratio 0.75,
+        // src/GaussianPyramid.cpp:95-100); deeper pyramids chain through finer levels (:101-106): build those in order
+        bool from_level0 = true;
+        for (int i = 1; i < levels; i++) from_level0 = from_level0 && plan[i].src_level == 0;
+        const Taps g5 = smooth5_taps();
+        const auto build_level = [&](int i) -> int {
+            if (i == 0) return PAPOF_OK;
+            const PyrPlan& q = plan[i];
+            const Taps g = gaussian_taps(q.sigma, q.fsize);
+            for (int second = (op == kSeqNext ? 1 : 0); second < 2; second++) {
+                const double* src = second ? L[q.src_level].p2 : L[q.src_level].p1;
+                double* dst = second ? L[i].p2 : L[i].p1;
+                PAPOF_TRY(filter_h(h, src, tmp_a, q.sh, q.sw, C, g));
+                PAPOF_TRY(filter_v(h, tmp_a, tmp_b, q.sh, q.sw, C, g));
+                PAPOF_TRY(resize(h, tmp_b, dst, q.sh, q.sw, C, L[i].h, L[i].w, q.rate, q.rate, false, 0.0));
+            }
+            return PAPOF_OK;
+        };
+        if (!from_level0)
+            for (int i = 1; i < levels; i++) PAPOF_TRY(build_level(i));
+        for (int k = levels - 1; k >= 0; k--) {
+            if (from_level0) PAPOF_TRY(build_level(k));
+            PAPOF_TRY(im2feature(h, L[k].p1, F1[k], L[k].h, L[k].w, C));
+            PAPOF_TRY(im2feature(h, L[k].p2, F2[k], L[k].h, L[k].w, C));
+            PAPOF_TRY(filter_h(h, F1[k], prep_tmp, L[k].h, L[k].w, fc, g5));
+            PAPOF_TRY(filter_v(h, prep_tmp, S1[k], L[k].h, L[k].w, fc, g5));
+            if (overlap) PAPOF_HIP(hipEventRecord(h->sync_events[k], prep));
+        }
         const Taps c3 = central3_taps();
         PAPOF_TRY(filter_h(h, L[0].p2, gx, H, W, C, c3));
         PAPOF_TRY(filter_v(h, L[0].p2, gy, H, W, C, c3));
         PAPOF_TRY(filter_v(h, gx, gxy, H, W, C, c3));
+        if (overlap) PAPOF_HIP(hipEventRecord(h->sync_events[levels], prep));
+        return PAPOF_OK;
+    };
+    if (overlap) {  // the preparation starts after whatever the caller queued on the main stream (the frame uploads)
+        PAPOF_HIP(hipEventRecord(h->sync_events[levels + 1], main_stream));
+        PAPOF_HIP(hipStreamWaitEvent(prep, h->sync_events[levels + 1], 0));
+    }
+    {
+        const int rc = prepare();
+        if (rc != PAPOF_OK) {
+            if (overlap) hipStreamSynchronize(prep);
+            return rc;
+        }
+    }
+
+    int pw = 0, ph = 0;
+    int rc_main = PAPOF_OK;
+    const auto solve_levels = [&]() -> int {
+        for (int k = levels - 1; k >= 0; k--) {
+            clk.phase(PAPOF_T_ALLOCATION);
+            const int lw = L[k].w, lh = L[k].h;
+            const size_t np = (size_t)lw * lh;
+            if (overlap) PAPOF_HIP(hipStreamWaitEvent(main_stream, h->sync_events[k], 0));
+            const double *f1 = F1[k], *f2 = F2[k];
+            if (k == levels - 1) {  // src/OpticalFlow.cpp:801-806
+                PAPOF_HIP(hipMemsetAsync(u, 0, np * sizeof(double), h->stream));
+                PAPOF_HIP(hipMemsetAsync(v, 0, np * sizeof(double), h->stream));
+                PAPOF_HIP(hipMemcpyAsync(warp, f2, np * fc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            } else {  // :809-814
+                const double xr = (double)lw / pw, yr = (double)lh / ph, inv = 1 / ratio;
+                PAPOF_TRY(resize(h, u, u2, ph, pw, 1, lh, lw, xr, yr, true, inv));
+                PAPOF_TRY(resize(h, v, v2, ph, pw, 1, lh, lw, xr, yr, true, inv));
+                std::swap(u, u2);
+                std::swap(v, v2);
+                PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc));
+            }
+            PAPOF_TRY(sor_bind(B.sp, lh, lw, P.n_sor + k * P.n_sor_per_level));
+            PAPOF_TRY(sor_reset_planes(h, B.sp));
+            PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, lh, lw, fc, P.alpha, P.n_outer + k * P.n_outer_per_level,
+                                  P.n_inner, P.n_sor + k * P.n_sor_per_level, P.omega, P.sor_mode, B, clk, sorclk,
+                                  S1[k]));
+            pw = lw;
+            ph = lh;
+        }
+        clk.phase(PAPOF_T_POSTPROCESSING);  // src/OpticalFlow.cpp:841-842
+        if (overlap) PAPOF_HIP(hipStreamWaitEvent(main_stream, h->sync_events[levels], 0));
         PAPOF_TRY(bicubic_warp(h, L[0].p1, L[0].p2, gx, gy, gxy, u, v, d_warp, H, W, C));
         PAPOF_HIP(hipMemcpyAsync(d_vx, u, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         PAPOF_HIP(hipMemcpyAsync(d_vy, v, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        return PAPOF_OK;
+    };
+    rc_main = solve_levels();
+    if (rc_main != PAPOF_OK) {  // never leave work of this call running on either stream
+        hipStreamSynchronize(main_stream);
+        if (overlap) hipStreamSynchronize(prep);
+        return rc_main;
     }
     clk.phase(-1);
     total.phase(-1);
@@ -417,6 +504,12 @@ int papof_create(int device, papof_handle** out) {
         delete h;
         return PAPOF_ENODEVICE;
     }
+    if ((e = hipStreamCreateWithFlags(&h->prep_stream, hipStreamNonBlocking)) != hipSuccess) {
+        set_last_error("hipStreamCreate", e, __FILE__, __LINE__);
+        papof_destroy(h);
+        return PAPOF_ENODEVICE;
+    }
+    if (const char* cs = std::getenv("PAPOF_OVERLAP")) h->overlap_prep = std::atoi(cs) != 0;
     if (const char* cs = std::getenv("PAPOF_HOST_THREADS")) h->host_threads = std::max(1, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_SOR_DEPTH")) h->sor_depth = std::max(8, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_SOR_XCD")) h->sor_xcd_affine = std::atoi(cs) != 0;
@@ -433,7 +526,10 @@ void papof_destroy(papof_handle* h) {
     if (!h) return;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    if (h->prep_stream) hipStreamSynchronize(h->prep_stream);
     for (hipEvent_t e : h->events) hipEventDestroy(e);
+    for (hipEvent_t e : h->sync_events) hipEventDestroy(e);
+    if (h->prep_stream) hipStreamDestroy(h->prep_stream);
     if (h->arena.base) hipFree(h->arena.base);
     if (h->sync_words) hipFree(h->sync_words);
     if (h->stage_dev) hipFree(h->stage_dev);
@@ -505,7 +601,7 @@ SeqOp seq_op_for(papof_handle* h, int H, int W, int C, int levels, const papof_p
     double ratio = P.ratio;
     if (ratio > 0.98 || ratio < 0.4) ratio = 0.75;
     if (levels < 1) return kSeqPrime;
-    const size_t need = arena_bytes_for(H, W, C, levels, P.n_sor + (levels - 1) * P.n_sor_per_level);
+    const size_t need = arena_bytes_for(H, W, C, levels, P.n_sor + (levels - 1) * P.n_sor_per_level, P.ratio);
     return seq_matches(h, H, W, C, levels, ratio, need) ? kSeqNext : kSeqPrime;
 }
 

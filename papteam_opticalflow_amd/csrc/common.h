@@ -151,6 +151,11 @@ struct papof_handle {
     int host_threads = 4;            // threads used to move pageable user buffers to / from the pinned buffers
     bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
     int sor_depth = 10;              // software-pipeline depth R (steps) of the exact-order SOR kernel
+    // second stream for everything that does not depend on the flow (pyramids, features, smoothed frame 1 of every
+    // level, derivative planes of the final bicubic warp): runs beside the coarse levels' latency-bound solves
+    hipStream_t prep_stream = nullptr;
+    std::vector<hipEvent_t> sync_events;  // untimed events ordering the two streams
+    bool overlap_prep = true;
     bool sor_xcd_affine = true;      // all sweeps of a band on one XCD (block index -> task mapping, speed only)
     // sequence mode (papof_seq_*): the pyramid of the last pushed frame stays in the arena and becomes "frame 1" of
     // the next pair.  Valid only while the arena block, the frame shape and the pyramid plan stay the same.

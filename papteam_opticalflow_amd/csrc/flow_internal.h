@@ -64,7 +64,7 @@ struct PyrPlan {
 };
 
 
-size_t arena_bytes_for(int H, int W, int C, int levels, int n_sor_max);
+size_t arena_bytes_for(int H, int W, int C, int levels, int n_sor_max, double ratio);
 int ensure_arena(papof_handle* h, size_t bytes);
 int check_params(const papof_params& P, int levels);
 int pyramid_plan(int H, int W, double ratio, int nlev, std::vector<Level>& L, std::vector<PyrPlan>& plan);

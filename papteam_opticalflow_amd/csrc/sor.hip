@@ -116,7 +116,7 @@ __global__ void k_xlane_probe(int* out) {  // out[0..63] = from_above, out[64..1
 
 // Diagnostic (PAPOF_PROBE=1 at handle creation): cost of the per-step arithmetic alone, one wave, no memory.
 // out[0] = s_memtime ticks, out[1] = s_memrealtime ticks (100 MHz) for `n` steps.
-__global__ __launch_bounds__(64) void k_alu_probe(unsigned long long* out, double* sink, int n, double seed) {
+__global__ __launch_bounds__(1024) void k_alu_probe(unsigned long long* out, double* sink, int n, double seed) {
     double duL = seed, dvL = seed * 0.5, phiL = 0.7, duC = 0.1, dvC = 0.2;
     const double phiC = 0.9, xy = 0.01, a1 = 0.3, a2 = 0.4, b1 = 0.001, b2 = 0.002, nalpha = -0.012, om1 = -0.8;
     double duR = 0.05 * seed, dvR = 0.06 * seed;
@@ -701,11 +701,11 @@ int sor_probe_dpp(papof_handle* h) {
     if (std::getenv("PAPOF_PROBE")) {
         unsigned long long* dt = nullptr;
         double* sink = nullptr;
-        if (hipMalloc((void**)&dt, 16) == hipSuccess && hipMalloc((void**)&sink, 64 * 8) == hipSuccess) {
-            for (int rep = 0; rep < 4; rep++) {
+        if (hipMalloc((void**)&dt, 16) == hipSuccess && hipMalloc((void**)&sink, 1024 * 8) == hipSuccess) {
+            for (int rep = 0; rep < 5; rep++) {  // 1, 2, 4, 8, 16 waves of ONE workgroup = one CU: does its fp64 issue scale?
                 const int n = 200000;
-                const int lanes = rep == 0 ? 64 : (rep == 1 ? 48 : (rep == 2 ? 32 : 16));
-                std::fprintf(stderr, "[papof probe] active lanes %d: ", lanes);
+                const int lanes = 64 << rep;
+                std::fprintf(stderr, "[papof probe] waves on one CU %d: ", lanes / 64);
                 hipLaunchKernelGGL(k_alu_probe, dim3(1), dim3(lanes), 0, h->stream, dt, sink, n, 1.0 + rep);
                 unsigned long long t[2] = {0, 0};
                 hipMemcpyAsync(t, dt, 16, hipMemcpyDeviceToHost, h->stream);

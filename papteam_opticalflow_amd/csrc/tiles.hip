@@ -369,7 +369,7 @@ int tiles_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     PAPOF_TRY(pyramid_plan(H, W, P.ratio, levels, L, plan));
     const int n_sor_max = P.n_sor + (levels - 1) * P.n_sor_per_level;
     h->seq.valid = false;
-    PAPOF_TRY(ensure_arena(h, arena_bytes_for(H, W, C, levels, n_sor_max) + (size_t)H * W * C * sizeof(double)));
+    PAPOF_TRY(ensure_arena(h, arena_bytes_for(H, W, C, levels, n_sor_max, P.ratio) + (size_t)H * W * C * sizeof(double)));
     Arena& A = h->arena;
     A.off = 0;
     A.overflow = false;
