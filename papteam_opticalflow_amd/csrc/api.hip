@@ -46,7 +46,7 @@ size_t arena_bytes_for(int H, int W, int C, int levels, int n_sor_max, double ra
         if (levels >= 1 && pyramid_plan(H, W, ratio, levels, L, plan) == PAPOF_OK)
             for (const Level& l : L) per_level += ((size_t)l.w * l.h * fc * sizeof(double) + 256) * 3;
     }
-    const SkewDims sd = skew_dims(H, W, n_sor_max);
+    const SkewDims sd = skew_dims(H, W, n_sor_max, 2);
     size_t planes = 0;
     planes += (size_t)2 * C * 5;           // two pyramids: sum of ratio^(2i) < 2.3 for ratio<=.75; 5 is safe to .98
     if (levels > 8) planes += (size_t)2 * C * levels;  // (ratio .98 decays slowly: bound by level count)
@@ -55,7 +55,7 @@ size_t arena_bytes_for(int H, int W, int C, int levels, int n_sor_max, double ra
     planes += 8;                           // u, v, resized u, v, phi + slack
     planes += (size_t)3 * C + C;           // bicubic derivative planes + interleaved output
     size_t bytes = planes * np * sizeof(double);
-    bytes += 3 * (sd.n + 2 * kLanes) * 16 + (sd.nd + 2 * kLanes) * 16 + 10 * np * sizeof(double);  // SOR operands
+    bytes += 3 * (sd.n + 2 * kLanes) * 16 + (sd.nd + sd.nh + 2 * kLanes) * 16 + 10 * np * sizeof(double);  // SOR operands
     bytes += per_level + np * fc * sizeof(double);  // + the preparation stream's own filter temporary
     bytes += (size_t)64 * 4096;            // alignment slack
     return bytes;
@@ -387,7 +387,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
                 std::swap(v, v2);
                 PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc));
             }
-            PAPOF_TRY(sor_bind(B.sp, lh, lw, P.n_sor + k * P.n_sor_per_level));
+            PAPOF_TRY(sor_bind(h, B.sp, lh, lw, P.n_sor + k * P.n_sor_per_level));
             PAPOF_TRY(sor_reset_planes(h, B.sp));
             PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, lh, lw, fc, P.alpha, P.n_outer + k * P.n_outer_per_level,
                                   P.n_inner, P.n_sor + k * P.n_sor_per_level, P.omega, P.sor_mode, B, clk, sorclk,
@@ -511,7 +511,8 @@ int papof_create(int device, papof_handle** out) {
     }
     if (const char* cs = std::getenv("PAPOF_OVERLAP")) h->overlap_prep = std::atoi(cs) != 0;
     if (const char* cs = std::getenv("PAPOF_HOST_THREADS")) h->host_threads = std::max(1, std::atoi(cs));
-    if (const char* cs = std::getenv("PAPOF_SOR_DEPTH")) h->sor_depth = std::max(8, std::atoi(cs));
+    if (const char* cs = std::getenv("PAPOF_SOR_DEPTH")) h->sor_depth = std::max(4, std::atoi(cs));
+    if (const char* cs = std::getenv("PAPOF_SOR_GROUP")) h->sor_group = std::max(1, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_SOR_XCD")) h->sor_xcd_affine = std::atoi(cs) != 0;
     int rc = sor_probe_dpp(h);
     if (rc != PAPOF_OK) {
@@ -1066,7 +1067,7 @@ int papof_stage_laplacian(papof_handle* h, const double* in, const double* weigh
 namespace {
 int alloc_sor_planes(Scope& S, int H, int W, int mode, int n_sor, SorPlanes& sp) {
     int rc = sor_alloc_planes(S.h->arena, H, W, mode, n_sor, sp);
-    if (rc == PAPOF_OK) rc = sor_bind(sp, H, W, n_sor);
+    if (rc == PAPOF_OK) rc = sor_bind(S.h, sp, H, W, n_sor);
     if (rc != PAPOF_OK) S.rc = rc;
     return S.rc;
 }
@@ -1079,7 +1080,7 @@ int papof_stage_sor(papof_handle* h, const double* phi, const double* imdxy, con
         n_sor < 1 || sor_mode < PAPOF_SOR_EXACT || sor_mode > PAPOF_SOR_JACOBI)
         return PAPOF_EINVAL;
     const size_t np = (size_t)height * width;
-    Scope S(h, img_bytes(height, width, 1, 16) + 4 * (skew_dims(height, width, n_sor).n + 128) * 16 + (skew_dims(height, width, n_sor).nd + 128) * 16 +
+    Scope S(h, img_bytes(height, width, 1, 16) + 4 * (skew_dims(height, width, n_sor).n + 128) * 16 + (skew_dims(height, width, n_sor, 2).nd + skew_dims(height, width, n_sor, 2).nh + 128) * 16 +
                    12 * (size_t)height * width * sizeof(double));
     PAPOF_TRY(S.rc);
     double* p = S.up_planar(phi, height, width, 1);
@@ -1109,7 +1110,7 @@ int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2
         return PAPOF_EINVAL;
     if (n_inner < 1) return PAPOF_EINVAL;
     Scope S(h, img_bytes(height, width, c, 12) + img_bytes(height, width, 1, 8) +
-                   4 * (skew_dims(height, width, n_sor).n + 128) * 16 + (skew_dims(height, width, n_sor).nd + 128) * 16 +
+                   4 * (skew_dims(height, width, n_sor).n + 128) * 16 + (skew_dims(height, width, n_sor, 2).nd + skew_dims(height, width, n_sor, 2).nh + 128) * 16 +
                    12 * (size_t)height * width * sizeof(double));
     PAPOF_TRY(S.rc);
     double* f1 = S.up_planar(im1, height, width, c);
@@ -1120,7 +1121,7 @@ int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2
     PAPOF_TRY(S.rc);
     SolveBuffers B;
     PAPOF_TRY(alloc_solve_buffers(h->arena, height, width, c, sor_mode, n_sor, B));
-    PAPOF_TRY(sor_bind(B.sp, height, width, n_sor));
+    PAPOF_TRY(sor_bind(h, B.sp, height, width, n_sor));
     PAPOF_TRY(sor_reset_planes(h, B.sp));
     PhaseClock clk{h, false}, sorclk{h, false};
     PAPOF_TRY(smooth_flow(h, f1, f2, w, du, dv, height, width, c, alpha, n_outer, n_inner, n_sor, omega, sor_mode, B,
@@ -1162,7 +1163,7 @@ int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_m
         sor_mode > PAPOF_SOR_JACOBI)
         return PAPOF_EINVAL;
     const size_t np = (size_t)height * width;
-    Scope S(h, img_bytes(height, width, 1, 16) + 4 * (skew_dims(height, width, n_sor).n + 128) * 16 + (skew_dims(height, width, n_sor).nd + 128) * 16 +
+    Scope S(h, img_bytes(height, width, 1, 16) + 4 * (skew_dims(height, width, n_sor).n + 128) * 16 + (skew_dims(height, width, n_sor, 2).nd + skew_dims(height, width, n_sor, 2).nh + 128) * 16 +
                    12 * (size_t)height * width * sizeof(double));
     PAPOF_TRY(S.rc);
     std::vector<double> host(np * 6);
@@ -1199,6 +1200,23 @@ int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_m
     hipEventDestroy(e1);
     if (sor_mode == PAPOF_SOR_EXACT) PAPOF_TRY(sor_check(h));
     *ms_per_solve = (double)ms / reps;
+    if (std::getenv("PAPOF_SOR_DBG") && sor_mode == PAPOF_SOR_EXACT && sp.sd.group > 1) {  // per-task wait statistics
+        const size_t ntask = (size_t)sp.sd.nb * n_sor;
+        PAPOF_HIP(hipMalloc((void**)&h->sor_dbg, ntask * 4 * sizeof(unsigned long long)));
+        PAPOF_HIP(hipMemset(h->sor_dbg, 0, ntask * 4 * sizeof(unsigned long long)));
+        PAPOF_TRY(sor_solve(h, sp, height, width, 0.012, 1.8, n_sor, sor_mode));
+        PAPOF_HIP(hipStreamSynchronize(h->stream));
+        std::vector<unsigned long long> st(ntask * 4);
+        PAPOF_HIP(hipMemcpy(st.data(), h->sor_dbg, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        hipFree(h->sor_dbg);
+        h->sor_dbg = nullptr;
+        for (int k = 0; k < n_sor && k < 8; k++)
+            for (int b = 0; b < sp.sd.nb && b < 3; b++) {
+                const unsigned long long* o = &st[((size_t)k * sp.sd.nb + b) * 4];
+                std::fprintf(stderr, "[sor dbg] sweep %2d band %2d: total %8.1f us  wait_covered %7.1f  lds_in %7.1f  lds_out %7.1f\n",
+                             k, b, o[0] / 2400.0, o[1] / 2400.0, o[2] / 2400.0, o[3] / 2400.0);
+            }
+    }
     return PAPOF_OK;
 }
 

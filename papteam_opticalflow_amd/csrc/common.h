@@ -102,9 +102,13 @@ struct SkewDims {
     size_t n;    // cells per paired coefficient plane
     int n_sor;   // sweeps this layout was made for
     int npos_d;  // positions of the (du, dv) planes
-    size_t nd;   // cells of the (du, dv) allocation (both parities)
+    size_t nd;   // cells of the two (du, dv) planes (ping-pong)
+    int group;   // sweeps per workgroup of the solver: 1 = one wave per workgroup; M > 1 = M consecutive sweeps of a band
+                 // in one workgroup, handed from wave to wave through LDS (sor.hip); the planes then alternate per GROUP
+    int dpar;    // which plane holds the values of the last sweep
+    size_t nh;   // grouped solver: cells of the halo rows H[sweep][band][position] that follow the two planes
 };
-inline SkewDims skew_dims(int h, int w, int n_sor) {
+inline SkewDims skew_dims(int h, int w, int n_sor, int group = 1) {
     SkewDims d;
     d.nb = (h + n_sor - 1 + kBandRows - 1) / kBandRows;
     d.ns = w + kLanes - 1;
@@ -113,8 +117,11 @@ inline SkewDims skew_dims(int h, int w, int n_sor) {
     d.npos = d.qt + d.ns + 2 * kSorMaxDepth + 2 + kBandRows * (d.nb - 1) + 2;
     d.n = (size_t)d.npos * d.hp;
     d.n_sor = n_sor;
-    d.npos_d = d.ns + 2 * kSorMaxDepth + 4;
+    d.npos_d = d.ns + 2 * kSorMaxDepth + 72;  // every position a task can touch, prefetch beyond the last step included
     d.nd = (size_t)2 * d.npos_d * d.nb * kLanes;
+    d.group = group < 1 ? 1 : group;
+    d.dpar = d.group == 1 ? ((n_sor - 1) & 1) : (((n_sor + d.group - 1) / d.group - 1) & 1);
+    d.nh = d.group == 1 ? 0 : (size_t)n_sor * d.nb * d.npos_d;
     return d;
 }
 
@@ -151,6 +158,8 @@ struct papof_handle {
     int host_threads = 4;            // threads used to move pageable user buffers to / from the pinned buffers
     bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
     int sor_depth = 10;              // software-pipeline depth R (steps) of the exact-order SOR kernel
+    unsigned long long* sor_dbg = nullptr;  // device buffer for per-task wait statistics (PAPOF_SOR_DBG)
+    int sor_group = 0;               // consecutive sweeps of a band per workgroup: 1, 2 or 4; 0 = by problem size
     // second stream for everything that does not depend on the flow (pyramids, features, smoothed frame 1 of every
     // level, derivative planes of the final bicubic warp): runs beside the coarse levels' latency-bound solves
     hipStream_t prep_stream = nullptr;
@@ -210,7 +219,8 @@ int sor_redblack_halfsweep(papof_handle* h, const SorPlanes& sp, int H, int W, d
                            const Rect& r);
 int sor_check(papof_handle* h);  // after a stream sync: PAPOF_ETIMEOUT if a device-side wait expired
 int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes& sp);  // carve the operand planes
-int sor_bind(SorPlanes& sp, int H, int W, int n_sor);          // choose the layout of the next solves (skew mode)
+int sor_bind(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor);  // choose the layout of the next solves (skew mode)
+int sor_group_size(const papof_handle* h, int H, int W, int n_sor);   // sweeps per workgroup the solver will use
 int sor_reset_planes(papof_handle* h, const SorPlanes& sp);    // zero all padding of the bound layout
 int sor_probe_dpp(papof_handle* h);  // sets h->use_dpp after checking the cross-lane DPP semantics on the device
 

@@ -210,6 +210,7 @@ __global__ void k_smooth_v_blend(const double* __restrict__ tmp, const double* _
 struct SkewIdx {
     int hp, qt, rt;        // coefficient planes
     int nb, npos_d, klast; // (du, dv) planes: bands, positions, index of the last sweep
+    int dpar;              // which of the two (du, dv) planes holds the last sweep's values
 };
 __device__ __forceinline__ size_t skew_cell(int i, int j, const SkewIdx& k) {
     return (size_t)(i + j + k.qt) * k.hp + (size_t)(i + k.rt);
@@ -222,7 +223,7 @@ __device__ __forceinline__ size_t sor_index(int i, int j, int W, const SkewIdx& 
 // cell of (du, dv)(i, j) after the last sweep in the banded ping-pong planes (common.h)
 __device__ __forceinline__ size_t dudv_cell(int i, int j, const SkewIdx& k) {
     const int t = i + k.klast, b = t / kBandRows, c = 1 + (t - b * kBandRows);
-    const size_t parity = (size_t)(k.klast & 1) * k.npos_d * k.nb * kLanes;
+    const size_t parity = (size_t)k.dpar * k.npos_d * k.nb * kLanes;
     return parity + ((size_t)(j + c + 1) * k.nb + b) * kLanes + c;
 }
 
@@ -740,13 +741,13 @@ int smooth_v_blend(papof_handle* h, const double* tmp, const double* im1s, doubl
 }
 
 static SkewIdx skew_idx(const SorPlanes& sp) {
-    return SkewIdx{sp.sd.hp, sp.sd.qt, sp.sd.rt, sp.sd.nb, sp.sd.npos_d, sp.sd.n_sor - 1};
+    return SkewIdx{sp.sd.hp, sp.sd.qt, sp.sd.rt, sp.sd.nb, sp.sd.npos_d, sp.sd.n_sor - 1, sp.sd.dpar};
 }
 
 // `prev` = operands of the previous inner iteration's solve (nullptr in the first one: du = dv = 0)
 static Increment increment_of(const SorPlanes* prev) {
-    if (!prev) return Increment{nullptr, nullptr, 0, SkewIdx{0, 0, 0, 0, 0, 0}};
-    return Increment{prev->du, prev->dv, prev->skew ? 1 : 0, prev->skew ? skew_idx(*prev) : SkewIdx{0, 0, 0, 0, 0, 0}};
+    if (!prev) return Increment{nullptr, nullptr, 0, SkewIdx{0, 0, 0, 0, 0, 0, 0}};
+    return Increment{prev->du, prev->dv, prev->skew ? 1 : 0, prev->skew ? skew_idx(*prev) : SkewIdx{0, 0, 0, 0, 0, 0, 0}};
 }
 
 int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlanes* prev, double* phi, int H, int W,
@@ -827,7 +828,7 @@ int sor_prep(papof_handle* h, const double* phi, const double* imdxy, const doub
                            out.b2);
     else
         hipLaunchKernelGGL(k_sor_prep<false>, grid2d(W, H), dim3(BX, BY), 0, h->stream, phi, imdxy, imdx2, imdy2,
-                           rhs1, rhs2, H, W, alpha, omega, SkewIdx{0, 0, 0, 0, 0, 0}, out.phi, out.xy, out.a1, out.a2, out.b1,
+                           rhs1, rhs2, H, W, alpha, omega, SkewIdx{0, 0, 0, 0, 0, 0, 0}, out.phi, out.xy, out.a1, out.a2, out.b1,
                            out.b2);
     LAUNCH_CHECK();
     return PAPOF_OK;
@@ -839,7 +840,7 @@ int sor_unpack(papof_handle* h, const SorPlanes& sp, double* du, double* dv, int
                            skew_idx(sp));
     else
         hipLaunchKernelGGL(k_sor_unpack<false>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, du, dv, H,
-                           W, SkewIdx{0, 0, 0, 0, 0, 0});
+                           W, SkewIdx{0, 0, 0, 0, 0, 0, 0});
     LAUNCH_CHECK();
     return PAPOF_OK;
 }

@@ -222,6 +222,16 @@ struct State {
     double duL, dvL, phiL, duC, dvC;
 };
 
+// A value that outlives the operand slot it came from is MOVED out of the slot's registers (an opaque v_mov the
+// compiler cannot fold away).  Otherwise the slot's registers stay live across the refill, the refill lands in other
+// registers, and the loop-carried slots need register copies at the top of every iteration -- which the compiler
+// guards with `s_waitcnt vmcnt(0)`: a full drain of the software pipeline once per iteration.
+__device__ __forceinline__ double moved(double x) {
+    double y;
+    asm volatile("v_mov_b64 %0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+
 template <int R, int t, bool DPP>
 __device__ __forceinline__ void step(const ExactArgs& A, const Task& T, const LaneOffs& L, double om1, int s,
                                      Slots<R>& c, State& S) {
@@ -253,9 +263,9 @@ __device__ __forceinline__ void step(const ExactArgs& A, const Task& T, const La
     __builtin_amdgcn_raw_buffer_store_b128(as_u4(duN, dvN), T.rd, L.st, (unsigned)s * L.pos_d, kAuxSc1);
     S.duL = duN;
     S.dvL = dvN;
-    S.phiL = phiC;
-    S.duC = duR;
-    S.dvC = dvR;
+    S.phiL = moved(phiC);
+    S.duC = moved(duR);
+    S.dvC = moved(dvR);
     asm volatile("" ::: "memory");  // keep this step's store ahead of its refill loads in the instruction stream
     load_slot<R, t>(T, L, s + R, c);  // refill this slot for the step R ahead
 }
@@ -340,7 +350,7 @@ __device__ __forceinline__ bool wait_covered(const ExactArgs& A, Polls& pl, cons
 
 template <int R, bool DPP>
 __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
-    static_assert(R >= 8 && R % 2 == 0, "two markers per iteration, each consumed 3 steps later");
+    static_assert(R >= 4 && R % 2 == 0, "two markers per iteration");
     const unsigned lane = threadIdx.x;
     // Workgroups are dealt round-robin over the 8 XCDs (blocks x and x + 8 share one; observed, speed only), so with
     // xcd_affine the sweeps of one band all run on one XCD: sweep k+1 re-reads the coefficient cells sweep k read a
@@ -416,35 +426,410 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     // MARKER loads: a 4-byte load issued right after the store of some step retires (vmcnt is in order) only after
     // that store has completed, so consuming it a few steps later proves the step complete and lets the task
     // publish it without draining the pipeline.  Two markers per iteration (after steps H-1 and R-1), each consumed
-    // D = 3 steps later: published progress lags the real one by 3..R/2+3 steps.  The marker reads the abort word,
-    // so a raised abort also ends every running task within one iteration.
-    constexpr int H = R / 2, DM = 3;
-    static_assert(H > DM, "marker distance must fit in half an iteration");
-    unsigned mb = 0u;
-    for (int i = 0; i < n_iter; ++i) {
-        if (i > 0 && !wait_covered(A, pl, D, (i + 2) * R)) return;
+    // DM = R - 3 steps later, in the next iteration: published progress lags the real one by R-3 .. R-3+R/2 steps.  The
+    // marker reads the abort word, so a raised abort also ends every running task within two iterations.
+    constexpr int H = R / 2, DM = R >= 6 ? R - 3 : H;
+    constexpr int CA = H + DM - R, CB = DM;  // steps of the NEXT iteration after which markers A / B are consumed
+    static_assert(CA >= 0 && CA < H && CB >= H && CB < R, "marker consumption points");
+    unsigned ma = 0u, mb = 0u;
+    // one iteration = R steps; `i` is only used for step numbers.  The first iteration is peeled off the loop so that the
+    // loop header joins two states with the same pipeline contents (after an iteration / after an iteration).
+    const auto iteration = [&](int i, bool first) -> bool {
+        if (!first && !wait_covered(A, pl, D, (i + 2) * R)) return false;
         const Polls pn = poll(D);  // poll for iteration i + 1
-        Seg<R, 0, DM, DPP>::run(A, T, L, om1, i * R, c, S);
-        if (i > 0) {  // marker issued after step i*R - 1
+        // Markers are consumed DM = R - 3 steps after they were issued -- i.e. in the NEXT iteration: consuming a marker
+        // waits (in-order vmcnt) for every load issued before it, and with DM = 3 that exposed ~0.35 us of latency twice
+        // per iteration (the refills issued in those 3 steps).  R - 3 steps later all of them have long arrived.
+        Seg<R, 0, CA, DPP>::run(A, T, L, om1, i * R, c, S);
+        if (!first) {  // marker A of the previous iteration: its steps < (i-1)R + H are complete
+            asm volatile("" ::"v"(ma), "v"(S.duL), "v"(S.dvL) : "memory");
+            if (ma != 0u) return false;
+            if (lane == 0)
+                __hip_atomic_store(my_prog, (unsigned)min(ns, (i - 1) * R + H), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        Seg<R, CA, H, DPP>::run(A, T, L, om1, i * R, c, S);
+        ma = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // marker A: after step H - 1
+        Seg<R, H, CB, DPP>::run(A, T, L, om1, i * R, c, S);
+        if (!first) {  // marker B of the previous iteration: steps < i R are complete
             asm volatile("" ::"v"(mb), "v"(S.duL), "v"(S.dvL) : "memory");
-            if (mb != 0u) return;
+            if (mb != 0u) return false;
             if (lane == 0)
                 __hip_atomic_store(my_prog, (unsigned)min(ns, i * R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        Seg<R, DM, H, DPP>::run(A, T, L, om1, i * R, c, S);
-        const unsigned ma = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        Seg<R, H, H + DM, DPP>::run(A, T, L, om1, i * R, c, S);
-        asm volatile("" ::"v"(ma), "v"(S.duL), "v"(S.dvL) : "memory");
-        if (ma != 0u) return;
-        if (lane == 0)
-            __hip_atomic_store(my_prog, (unsigned)min(ns, i * R + H), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        Seg<R, H + DM, R, DPP>::run(A, T, L, om1, i * R, c, S);
-        mb = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Seg<R, CB, R, DPP>::run(A, T, L, om1, i * R, c, S);
+        mb = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // marker B: after step R - 1
         pl = pn;
-    }
+        return true;
+    };
+    if (!iteration(0, true)) return;
+    for (int i = 1; i < n_iter; ++i)
+        if (!iteration(i, false)) return;
     // final publication: every store of this wave has left the CU before the counter moves (guide G16/R1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(my_prog, (unsigned)ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GROUPED exact-order solver: M consecutive sweeps of a band in ONE workgroup (temporal blocking).
+//
+// Same tasks, same lanes, same arithmetic and the same cross-workgroup protocol as k_sor_exact above -- but wave m of
+// workgroup (band b, group g) runs sweep k = g*M + m, and the sweep-to-sweep hand-off INSIDE a group goes through LDS
+// instead of HBM:
+//   * wave m writes each step's 64 (du, dv) cells into a 16-slot LDS ring and, once per half-iteration (H = R/2
+//     steps), advances an LDS progress word; wave m+1 waits for that word, reads the H blocks it needs (lane l <- cell
+//     l-1: the band climbed one row) and acknowledges them in a second word (write-after-read guard of the ring).
+//     A hand-off costs ~H steps instead of ~40 steps + three memory round trips, and it moves no HBM bytes;
+//   * only wave 0 of a group loads (du, dv) from the ping-pong planes (written by the LAST wave of the previous group,
+//     so the planes now alternate per group) and only the last wave stores them there; the coefficient operands of waves
+//     1..M-1 are the cache lines wave 0 pulled a few steps earlier (same CU: L1 / L2 hits);
+//   * what another BAND needs is one cell per step: the new value of the row above (ghost lane 0).  Every wave writes
+//     that cell (its lane 62) to a small halo row HALO[sweep][band][position] behind the two planes; being per sweep,
+//     halo rows are never reused, so the write-after-read dependency of k_sor_exact disappears.  The (du, dv) planes and
+//     the halo rows sit in one allocation and are addressed through one buffer descriptor with per-lane strides.
+// HBM traffic per cell-update drops from 80 B towards 80/M + 32/M B; the critical path loses (M-1)/M of its sweep hops.
+// fp64 issue is not the limit: 16 waves of this arithmetic on one CU each still take 244 cycles per step (measured).
+// ------------------------------------------------------------------------------------------------
+struct GroupArgs {
+    const double *phi, *a1, *b1;
+    double* du;
+    unsigned* prog;   // [n_sor][nb]
+    unsigned* abort;  // one word
+    int nb, ns, hp, npos, qt, rt, npos_d, n_sor;
+    int xcd_affine;
+    unsigned long long* dbg;  // diagnostics (PAPOF_SOR_DBG): per task {total, wait_covered, lds in, lds out} shader clocks
+    unsigned halo_off;  // byte offset of the halo rows from du
+    double nalpha, om1;
+};
+
+constexpr int kRing = 16;  // LDS ring slots of (du, dv) per producing wave (>= 2 half-iterations)
+
+struct GLane {  // per-lane constant byte offsets (VGPRs)
+    unsigned pa, pbc;      // coefficient cells (as LaneOffs)
+    unsigned pd, pd_step;  // (du, dv) right-old of step s at pd + s * pd_step   [kOob: LDS-fed lane]
+    unsigned st;           // store of step s at st + s * pos_d                   [kOob unless last wave of the group]
+    unsigned hs;           // halo store of step s at hs + s * 16                 [lane 62 only]
+    unsigned pos_c, pos_d;
+};
+
+template <int R>
+struct GSlots {
+    u32x4 pa[R], pb[R], pc[R], pd[R];
+};
+
+template <int R, int t>
+__device__ __forceinline__ void g_load_coef(const Task& T, const GLane& L, int s, GSlots<R>& c) {
+    const unsigned off = (unsigned)s * L.pos_c;
+    c.pa[t] = __builtin_amdgcn_raw_buffer_load_b128(T.ra, L.pa, off, kAuxPlain);
+    c.pb[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rb, L.pbc, off, kAuxPlain);
+    c.pc[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rc, L.pbc, off, kAuxPlain);
+}
+template <int R, int t>
+__device__ __forceinline__ void g_load_unknowns(const Task& T, const GLane& L, int s, GSlots<R>& c) {
+    c.pd[t] = __builtin_amdgcn_raw_buffer_load_b128(T.rd, L.pd + (unsigned)s * L.pd_step, 0, kAuxSc1);
+}
+
+// Role of a wave inside its group (compile-time: four straight-line variants of the sweep loop, chosen once per
+// wave by a scalar branch, so that the memory-counter bookkeeping of the software pipeline stays exact).
+//   FROM_LDS: (du, dv) of the previous sweep come from the ring of the wave before (else: from the planes)
+//   TO_LDS:   this sweep's (du, dv) go to the own ring (else: to the planes)
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+typedef __attribute__((address_space(3))) volatile unsigned lds_word;
+
+template <int R, int t, bool DPP, bool FROM_LDS, bool TO_LDS>
+__device__ __forceinline__ void g_step(const GroupArgs& A, const Task& T, const GLane& L, lds_u32x4* ring_out,
+                                       unsigned lane, double om1, int s, GSlots<R>& c, const u32x4 (&lpd)[R / 2],
+                                       State& S) {
+    const double nalpha = A.nalpha;
+    const D2 pa = as_d2(c.pa[t]), pb = as_d2(c.pb[t]), pc = as_d2(c.pc[t]);
+    u32x4 raw = c.pd[t];
+    if (FROM_LDS) {
+        const u32x4 l = lpd[t % (R / 2)];
+        raw = lane != 0 ? l : raw;
+    }
+    const D2 pd = as_d2(raw);
+    const double phiC = pa.x, xy = pa.y, duR = pd.x, dvR = pd.y;
+    const double duU = from_above<DPP>(S.duL);
+    const double dvU = from_above<DPP>(S.dvL);
+    const double phiU = from_above<DPP>(S.phiL);
+    const double duD = from_below<DPP>(duR);
+    const double dvD = from_below<DPP>(dvR);
+    double s1 = S.phiL * S.duL;
+    double s2 = S.phiL * S.dvL;
+    s1 += phiC * duR;
+    s2 += phiC * dvR;
+    s1 += phiU * duU;
+    s2 += phiU * dvU;
+    s1 += phiC * duD;
+    s2 += phiC * dvD;
+    s1 *= nalpha;
+    s2 *= nalpha;
+    s1 += xy * S.dvC;
+    const double duN = om1 * S.duC + pb.x * (pc.x - s1);
+    s2 += xy * duN;
+    const double dvN = om1 * S.dvC + pb.y * (pc.y - s2);
+    const u32x4 out = as_u4(duN, dvN);
+    if (TO_LDS)
+        ring_out[(s & (kRing - 1)) * kLanes + lane] = out;
+    else
+        __builtin_amdgcn_raw_buffer_store_b128(out, T.rd, L.st, (unsigned)s * L.pos_d, kAuxSc1);
+    __builtin_amdgcn_raw_buffer_store_b128(out, T.rd, L.hs + (unsigned)s * 16u, 0, kAuxSc1);  // lane 62 -> halo row
+    S.duL = duN;
+    S.dvL = dvN;
+    S.phiL = phiC;
+    S.duC = duR;
+    S.dvC = dvR;
+    asm volatile("" ::: "memory");
+    g_load_coef<R, t>(T, L, s + R, c);
+    g_load_unknowns<R, t>(T, L, s + R, c);
+}
+
+template <int R, int t0, int t1, bool DPP, bool FROM_LDS, bool TO_LDS>
+struct GSeg {
+    static __device__ __forceinline__ void run(const GroupArgs& A, const Task& T, const GLane& L, lds_u32x4* ring_out,
+                                               unsigned lane, double om1, int s0, GSlots<R>& c,
+                                               const u32x4 (&lpd)[R / 2], State& S) {
+        g_step<R, t0, DPP, FROM_LDS, TO_LDS>(A, T, L, ring_out, lane, om1, s0 + t0, c, lpd, S);
+        GSeg<R, t0 + 1, t1, DPP, FROM_LDS, TO_LDS>::run(A, T, L, ring_out, lane, om1, s0, c, lpd, S);
+    }
+};
+template <int R, int t1, bool DPP, bool FROM_LDS, bool TO_LDS>
+struct GSeg<R, t1, t1, DPP, FROM_LDS, TO_LDS> {
+    static __device__ __forceinline__ void run(const GroupArgs&, const Task&, const GLane&, lds_u32x4*, unsigned,
+                                               double, int, GSlots<R>&, const u32x4 (&)[R / 2], State&) {}
+};
+template <int R, int t>
+struct GFill {
+    static __device__ __forceinline__ void coef(const Task& T, const GLane& L, GSlots<R>& c) {
+        GFill<R, t - 1>::coef(T, L, c);
+        g_load_coef<R, t>(T, L, t, c);
+    }
+    static __device__ __forceinline__ void unknowns(const Task& T, const GLane& L, GSlots<R>& c) {
+        GFill<R, t - 1>::unknowns(T, L, c);
+        g_load_unknowns<R, t>(T, L, t, c);
+    }
+};
+template <int R>
+struct GFill<R, -1> {
+    static __device__ __forceinline__ void coef(const Task&, const GLane&, GSlots<R>&) {}
+    static __device__ __forceinline__ void unknowns(const Task&, const GLane&, GSlots<R>&) {}
+};
+
+// LDS progress words: the LDS unit executes a wave's operations in order, so cells written before a word are visible to
+// whoever has seen the word; an explicit lgkmcnt wait keeps the issue order.  Bounded like every other wait.
+__device__ __forceinline__ bool lds_wait_ge(const GroupArgs& A, lds_word* p, unsigned need) {
+    unsigned spins = 0;
+    while (*p < need) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0u) {
+            if (__hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > (kSpinLimit << 3)) {
+                __hip_atomic_store(A.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+
+struct GWaveCtx {  // wave-uniform
+    lds_u32x4 *ring_in, *ring_out;
+    lds_word *done_in, *taken_in, *done_out, *taken_out;
+    int task;  // k * nb + b (diagnostics)
+    unsigned* my_prog;
+    Deps D;
+    int ns, n_iter;
+};
+
+template <int R, bool DPP, bool FROM_LDS, bool TO_LDS>
+__device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, const GLane& L, const GWaveCtx& W,
+                                           unsigned lane, double om1) {
+    constexpr int H = R / 2, DM = 3;
+    static_assert(H > DM, "marker distance must fit in half an iteration");
+    const int ns = W.ns;
+    ExactArgs X;  // the waiting helpers only look at these
+    X.abort = A.abort;
+    X.ns = ns;
+    State S;
+    S.duL = S.dvL = S.phiL = 0.0;
+    GSlots<R> c;
+    u32x4 lpd[H];
+#pragma unroll
+    for (int q = 0; q < H; q++) lpd[q] = u32x4{0u, 0u, 0u, 0u};
+    const unsigned lcell = lane > 0 ? lane - 1u : 0u;  // lane l reads cell l - 1: the band climbed one row
+
+    unsigned long long t_cov = 0, t_in = 0, t_out = 0, t_start = 0;
+    const bool dbg = A.dbg != nullptr;
+    GFill<R, R - 1>::coef(T, L, c);
+    Polls pl = poll(W.D);
+    if (!wait_covered(X, pl, W.D, 2 * R)) return;
+    if (dbg) t_start = __builtin_amdgcn_s_memtime();
+    {  // centre of the first cells: position 0 (zero; LDS-fed lanes: the same zero), lane 0: halo position 63
+        const unsigned first = L.pd == kOob ? kOob : L.pd - L.pd_step;
+        const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, first, 0, kAuxSc1));
+        S.duC = c0.x;
+        S.dvC = c0.y;
+    }
+    GFill<R, R - 1>::unknowns(T, L, c);
+
+    // one half-iteration = H steps: LDS operands in, steps, progress words out
+    const auto half_begin = [&](int sa) -> bool {
+        if (FROM_LDS) {
+            const unsigned long long ta = dbg ? __builtin_amdgcn_s_memtime() : 0;
+            if (!lds_wait_ge(A, W.done_in, (unsigned)(sa + H))) return false;
+            if (dbg) t_in += __builtin_amdgcn_s_memtime() - ta;
+#pragma unroll
+            for (int q = 0; q < H; q++) lpd[q] = W.ring_in[((sa + q) & (kRing - 1)) * kLanes + lcell];
+        }
+        const unsigned long long tb = dbg ? __builtin_amdgcn_s_memtime() : 0;
+        if (TO_LDS && sa + H > kRing && !lds_wait_ge(A, W.taken_out, (unsigned)(sa + H - kRing))) return false;
+        if (dbg) t_out += __builtin_amdgcn_s_memtime() - tb;
+        return true;
+    };
+    const auto half_end = [&](int sa) {
+        if (FROM_LDS) {
+            asm volatile("" ::: "memory");
+            if (lane == 0) *W.taken_in = (unsigned)(sa + H);  // the H blocks are in registers and consumed
+        }
+        if (TO_LDS) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *W.done_out = (unsigned)(sa + H);
+        }
+    };
+
+    unsigned mb = 0u;
+    for (int i = 0; i < W.n_iter; ++i) {
+        const unsigned long long tc = dbg ? __builtin_amdgcn_s_memtime() : 0;
+        if (i > 0 && !wait_covered(X, pl, W.D, (i + 2) * R)) return;
+        if (dbg) t_cov += __builtin_amdgcn_s_memtime() - tc;
+        const Polls pn = poll(W.D);
+        const int s0 = i * R;
+        if (!half_begin(s0)) return;
+        GSeg<R, 0, DM, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
+        if (i > 0) {
+            asm volatile("" ::"v"(mb), "v"(S.duL), "v"(S.dvL) : "memory");
+            if (mb != 0u) return;
+            if (lane == 0)
+                __hip_atomic_store(W.my_prog, (unsigned)min(ns, s0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        GSeg<R, DM, H, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
+        const unsigned ma = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        half_end(s0);
+        if (!half_begin(s0 + H)) return;
+        GSeg<R, H, H + DM, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
+        asm volatile("" ::"v"(ma), "v"(S.duL), "v"(S.dvL) : "memory");
+        if (ma != 0u) return;
+        if (lane == 0)
+            __hip_atomic_store(W.my_prog, (unsigned)min(ns, s0 + H), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        GSeg<R, H + DM, R, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
+        mb = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        half_end(s0 + H);
+        pl = pn;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(W.my_prog, (unsigned)ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (dbg && lane == 0) {
+        unsigned long long* o = A.dbg + (size_t)W.task * 4;
+        o[0] = __builtin_amdgcn_s_memtime() - t_start;
+        o[1] = t_cov;
+        o[2] = t_in;
+        o[3] = t_out;
+    }
+}
+
+template <int R, int M, bool DPP>
+__global__ __launch_bounds__(64 * M) void k_sor_group(GroupArgs A) {
+    static_assert(R >= 8 && R % 2 == 0 && R <= kRing, "half-iterations of R/2 steps; the ring holds two of them");
+    __shared__ u32x4 ring[(M > 1 ? M - 1 : 1) * kRing * kLanes];
+    __shared__ unsigned lds_done[M];   // [m]: steps of wave m whose cells are in its ring
+    __shared__ unsigned lds_taken[M];  // [m]: steps of ring m the wave after has read
+    const unsigned lane = threadIdx.x & 63u;
+    const int m = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform by construction
+    if (lane == 0) {
+        lds_done[m] = 0u;
+        lds_taken[m] = 0u;
+    }
+    __syncthreads();  // the only barrier: every wave is still here
+    int g, b;
+    if (A.xcd_affine) {
+        const int x = blockIdx.x & 7, y = blockIdx.x >> 3, nb8 = (A.nb + 7) >> 3;
+        g = y / nb8;
+        b = (y - g * nb8) * 8 + x;
+        if (b >= A.nb) return;
+    } else {
+        g = blockIdx.x / A.nb;
+        b = blockIdx.x - g * A.nb;
+    }
+    const int k = g * M + m;
+    if (k >= A.n_sor) return;
+    const bool ghost = lane == 0 || lane == kLanes - 1;
+    const bool from_lds = m > 0, to_planes = m == M - 1 || k == A.n_sor - 1;
+    GWaveCtx W;
+    lds_u32x4* const ring3 = (lds_u32x4*)ring;
+    W.ring_in = ring3 + (m > 0 ? m - 1 : 0) * kRing * kLanes;
+    W.ring_out = ring3 + (m < M - 1 ? m : 0) * kRing * kLanes;
+    W.done_in = (lds_word*)&lds_done[m > 0 ? m - 1 : 0];
+    W.taken_in = (lds_word*)&lds_taken[m > 0 ? m - 1 : 0];
+    W.done_out = (lds_word*)&lds_done[m];
+    W.taken_out = (lds_word*)&lds_taken[m];
+    W.task = k * A.nb + b;
+    W.ns = A.ns;
+    W.n_iter = (A.ns + R - 1) / R;
+
+    Task T;
+    const unsigned plane_bytes = (unsigned)(((size_t)A.npos * A.hp + kLanes) * 16u);
+    constexpr unsigned kBlock = kLanes * 16u;
+    const unsigned par_bytes = (unsigned)A.npos_d * (unsigned)A.nb * kBlock;
+    const unsigned all_bytes = A.halo_off + (unsigned)A.n_sor * (unsigned)A.nb * (unsigned)A.npos_d * 16u;
+    T.ra = __builtin_amdgcn_make_buffer_rsrc((void*)A.phi, 0, plane_bytes, 0x00020000);
+    T.rb = __builtin_amdgcn_make_buffer_rsrc((void*)A.a1, 0, plane_bytes, 0x00020000);
+    T.rc = __builtin_amdgcn_make_buffer_rsrc((void*)A.b1, 0, plane_bytes, 0x00020000);
+    T.rd = __builtin_amdgcn_make_buffer_rsrc((void*)A.du, 0, all_bytes, 0x00020000);
+    const int r0 = kBandRows * b - k - 1;
+    GLane L;
+    L.pos_c = (unsigned)A.hp * 16u;
+    L.pos_d = (unsigned)A.nb * kBlock;
+    const unsigned base = ((unsigned)(r0 + A.qt) * (unsigned)A.hp + (unsigned)(r0 + A.rt) + lane) * 16u;
+    L.pa = base;
+    L.pbc = ghost ? kOob : base;
+    // planes alternate per group: group g writes plane g & 1 and reads plane (g - 1) & 1
+    const unsigned mine = (unsigned)(g & 1) * par_bytes, prev = (unsigned)((g + 1) & 1) * par_bytes;
+    L.st = to_planes ? mine + L.pos_d + (unsigned)b * kBlock + lane * 16u : kOob;
+    const auto halo_row = [&](int kk, int bb) {  // byte offset of HALO[kk][bb][0]
+        return A.halo_off + (unsigned)((kk * A.nb + bb) * A.npos_d) * 16u;
+    };
+    if (lane == 0) {  // the row above, NEW value: lane 62 of (b-1, k), 63 steps ahead of ours -> halo position s + 64
+        L.pd = b > 0 ? halo_row(k, b - 1) + 64u * 16u : kOob;
+        L.pd_step = 16u;
+    } else if (from_lds) {
+        L.pd = kOob;
+        L.pd_step = 0u;
+    } else {  // wave 0: own block of the previous group's plane, cell lane - 1
+        L.pd = prev + L.pos_d + (unsigned)b * kBlock + (lane - 1u) * 16u;
+        L.pd_step = L.pos_d;
+    }
+    L.hs = (lane == kLanes - 2 && b + 1 < A.nb) ? halo_row(k, b) + 16u : kOob;  // step s -> position s + 1
+    const double om1 = ghost ? 1.0 : A.om1;
+
+    W.my_prog = A.prog + ((size_t)k * A.nb + b) * kProgStride;
+    W.D.has_own = m == 0 && k > 0;  // inside a group the previous sweep arrives through LDS
+    W.D.has_up = b > 0;
+    W.D.has_dn2 = false;            // planes are read by the own band only, halo rows are never reused
+    W.D.own = A.prog + ((size_t)(k - 1) * A.nb + b) * kProgStride;
+    W.D.up = A.prog + ((size_t)k * A.nb + (b - 1)) * kProgStride;
+    W.D.dn2 = W.D.own;
+    if (from_lds) {
+        if (to_planes)
+            g_run_wave<R, DPP, true, false>(A, T, L, W, lane, om1);
+        else
+            g_run_wave<R, DPP, true, true>(A, T, L, W, lane, om1);
+    } else {
+        if (to_planes)
+            g_run_wave<R, DPP, false, false>(A, T, L, W, lane, om1);
+        else
+            g_run_wave<R, DPP, false, true>(A, T, L, W, lane, om1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -529,11 +914,11 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
     if (n_sor <= 0) return PAPOF_EINVAL;
     if (mode == PAPOF_SOR_EXACT) {
         if (!sp.skew) return PAPOF_EINVAL;
-        const SkewDims sd = skew_dims(H, W, n_sor);
+        const SkewDims sd = skew_dims(H, W, n_sor, sp.sd.group);
         if (sd.hp != sp.sd.hp || sd.npos != sp.sd.npos || sd.qt != sp.sd.qt || sd.nb != sp.sd.nb ||
-            sd.n_sor != sp.sd.n_sor || sd.n > sp.cap_cells || sd.nd > sp.cap_cells_d)
+            sd.n_sor != sp.sd.n_sor || sd.n > sp.cap_cells || sd.nd + sd.nh > sp.cap_cells_d)
             return PAPOF_EINVAL;  // sor_bind() must have chosen this layout (the operands were assembled in it)
-        if ((sd.n + kLanes) * 16 >= (size_t(1) << 30) || sd.nd * 16 >= (size_t(1) << 30))
+        if ((sd.n + kLanes) * 16 >= (size_t(1) << 30) || (sd.nd + sd.nh) * 16 >= (size_t(1) << 30))
             return PAPOF_EINVAL;  // 32-bit byte offsets, see kOob
         const size_t words = (size_t)sd.nb * n_sor * kProgStride + kProgStride;
         if (words > h->sync_cap) {
@@ -574,7 +959,43 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.nalpha = nalpha;
         A.om1 = om1;
         // du = dv = 0 before the first sweep (src/OpticalFlow.cpp:452-453); also clears the ghost-lane mirrors
-        PAPOF_HIP(hipMemsetAsync(sp.du, 0, sd.nd * 16, h->stream));  // both parities
+        PAPOF_HIP(hipMemsetAsync(sp.du, 0, (sd.nd + sd.nh) * 16, h->stream));  // both planes (+ the halo rows)
+        if (sd.group > 1) {
+            GroupArgs Ga;
+            Ga.phi = sp.phi;
+            Ga.a1 = sp.a1;
+            Ga.b1 = sp.b1;
+            Ga.du = sp.du;
+            Ga.prog = prog;
+            Ga.abort = h->sync_words;
+            Ga.nb = sd.nb;
+            Ga.ns = sd.ns;
+            Ga.hp = sd.hp;
+            Ga.npos = sd.npos;
+            Ga.qt = sd.qt;
+            Ga.rt = sd.rt;
+            Ga.npos_d = sd.npos_d;
+            Ga.n_sor = n_sor;
+            Ga.halo_off = (unsigned)(sd.nd * 16);
+            Ga.dbg = h->sor_dbg;
+            Ga.nalpha = nalpha;
+            Ga.om1 = om1;
+            const int groups = (n_sor + sd.group - 1) / sd.group;
+            Ga.xcd_affine = (h->sor_xcd_affine && sd.nb <= 8) ? 1 : 0;
+            const dim3 ggrid(Ga.xcd_affine ? 8 * ((sd.nb + 7) / 8) * groups : sd.nb * groups);
+            if (sd.group == 4 && h->sor_depth >= 12)
+                hipLaunchKernelGGL((k_sor_group<12, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
+            else if (sd.group == 4 && h->sor_depth >= 10)
+                hipLaunchKernelGGL((k_sor_group<10, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
+            else if (sd.group == 4)
+                hipLaunchKernelGGL((k_sor_group<8, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
+            else if (sd.group == 2)
+                hipLaunchKernelGGL((k_sor_group<8, 2, true>), ggrid, dim3(kLanes * 2), 0, h->stream, Ga);
+            else
+                return PAPOF_EINVAL;
+            PAPOF_HIP(hipGetLastError());
+            return PAPOF_OK;
+        }
         // measured: with at most one band per XCD the affinity is worth 3-4 % (small pyramid levels); beyond that the
         // uneven band count per XCD costs more than the L2 hits give (1920x1080: 18 bands over 8 XCDs, -5 %)
         A.xcd_affine = (h->sor_xcd_affine && sd.nb <= 8) ? 1 : 0;
@@ -582,6 +1003,10 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         const int R = h->sor_depth;
         if (!h->use_dpp)
             hipLaunchKernelGGL((k_sor_exact<8, false>), grid, block, 0, h->stream, A);
+        else if (R <= 4)
+            hipLaunchKernelGGL((k_sor_exact<4, true>), grid, block, 0, h->stream, A);
+        else if (R <= 6)
+            hipLaunchKernelGGL((k_sor_exact<6, true>), grid, block, 0, h->stream, A);
         else if (R <= 8)
             hipLaunchKernelGGL((k_sor_exact<8, true>), grid, block, 0, h->stream, A);
         else if (R <= 10)
@@ -636,10 +1061,20 @@ int sor_reset_planes(papof_handle* h, const SorPlanes& sp) {
     return PAPOF_OK;  // the (du, dv) planes are cleared by every solve
 }
 
-int sor_bind(SorPlanes& sp, int H, int W, int n_sor) {
+// Sweeps per workgroup of the exact-order solver for this problem: the grouped kernel needs the verified DPP lane
+// shifts; PAPOF_SOR_GROUP = 1 selects the one-wave-per-workgroup kernel.
+int sor_group_size(const papof_handle* h, int H, int W, int n_sor) {
+    if (!h || !h->use_dpp || n_sor < 2) return 1;
+    int g = h->sor_group;
+    if (g == 0) g = 1;  // measured: grouping wins 5-20 % on isolated small solves, nothing end to end
+    if (g >= 4) return 4;  // LDS (160 KB) holds the rings of up to 4 waves... and 4 waves = one per SIMD
+    return g >= 2 ? 2 : 1;
+}
+
+int sor_bind(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor) {
     if (!sp.skew) return PAPOF_OK;
-    const SkewDims sd = skew_dims(H, W, n_sor);
-    if (sd.n > sp.cap_cells || sd.nd > sp.cap_cells_d) return PAPOF_ENOMEM;
+    const SkewDims sd = skew_dims(H, W, n_sor, sor_group_size(h, H, W, n_sor));
+    if (sd.n > sp.cap_cells || sd.nd + sd.nh > sp.cap_cells_d) return PAPOF_ENOMEM;
     sp.sd = sd;
     return PAPOF_OK;
 }
@@ -650,9 +1085,9 @@ int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes&
     sp.cap_cells = sp.cap_cells_d = 0;
     sp.sd = SkewDims{};
     if (sp.skew) {
-        sp.sd = skew_dims(H, W, n_sor_cap);
+        sp.sd = skew_dims(H, W, n_sor_cap, 2);  // any group size > 1: capacity includes the halo rows
         sp.cap_cells = sp.sd.n;
-        sp.cap_cells_d = sp.sd.nd;
+        sp.cap_cells_d = sp.sd.nd + sp.sd.nh;
         const size_t n = 2 * (sp.cap_cells + kLanes);  // doubles per paired plane
         sp.phi = A.f64(n);
         sp.xy = sp.phi ? sp.phi + 1 : nullptr;
@@ -728,7 +1163,7 @@ int sor_check(papof_handle* h) {
     unsigned flag = 0;
     PAPOF_HIP(hipMemcpy(&flag, h->sync_words, sizeof(unsigned), hipMemcpyDeviceToHost));
     if (flag != 0) {
-        PAPOF_HIP(hipMemset(h->sync_words, 0, 4 * sizeof(unsigned)));
+        PAPOF_HIP(hipMemset(h->sync_words, 0, sizeof(unsigned)));
         return PAPOF_ETIMEOUT;
     }
     return PAPOF_OK;

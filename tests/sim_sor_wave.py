@@ -196,3 +196,159 @@ def sor_coefficients(phi, imdx2, imdy2, alpha, omega):
     coeff[:-1, :] += phi[:-1, :]
     coeff *= alpha
     return omega / (imdx2 + alpha * 0.05 + coeff), omega / (imdy2 + alpha * 0.05 + coeff)
+
+
+def simulate_grouped(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, group=4, ring=16, seed=0):
+    """Model of the GROUPED kernel `k_sor_group<R, M>` (sor.hip): wave m of workgroup (band b, group g) runs sweep
+    k = g*M + m.  Inside a group the (du, dv) cells of a sweep reach the next sweep through a `ring`-slot LDS ring
+    guarded by two progress words per producing wave (`done`: steps written, published per half-iteration of R/2
+    steps; `taken`: steps the consumer has read -- the producer may be at most `ring` steps ahead).  Only wave 0 reads
+    the ping-pong planes (which alternate per GROUP) and only the last wave of a group writes them; the new value of the
+    row above (ghost lane 0) comes from per-sweep halo rows HALO[k][b][position] that lane 62 of every wave writes, so
+    no write-after-read dependency on the band below remains.  Cross-workgroup progress counters as in `simulate`.
+    Executed under a random scheduler at half-iteration granularity; loads are taken when the kernel issues them."""
+    h, w = phi.shape
+    lay = layout(h, w, n_sor, r)
+    nb, ns, rt, qt = lay["nb"], lay["ns"], lay["rt"], lay["qt"]
+    P = {n: to_skew(p, lay) for n, p in dict(phi=phi, xy=imdxy, a1=a1, a2=a2, b1=b1, b2=b2).items()}
+    half = r // 2
+    n_iter = (ns + r - 1) // r
+    n_total = n_iter * r
+    npos_d = ns + 2 * 32 + 72
+    D = np.zeros((2, 2, npos_d, nb, LANES))          # [du|dv][group parity][position][band][cell]
+    HALO = np.zeros((2, n_sor, nb, npos_d))          # [du|dv][sweep][band][position]
+    RING = np.zeros((2, n_sor, nb, ring, LANES))     # ring written by task (b, k) for (b, k+1) of the same group
+    prog = np.zeros((nb, n_sor), dtype=np.int64)
+    done = np.zeros((nb, n_sor), dtype=np.int64)     # LDS word: steps of (b, k) in its ring
+    taken = np.zeros((nb, n_sor), dtype=np.int64)    # LDS word: steps of ring (b, k) read by (b, k+1)
+    nalpha = -alpha
+    om1 = np.full(LANES, 1 - omega)
+    om1[0] = om1[63] = 1.0
+    real = np.zeros(LANES, dtype=bool)
+    real[1:63] = True
+    rng = np.random.default_rng(seed)
+
+    def role(k):
+        m = k % group
+        first = m == 0
+        last = m == group - 1 or k == n_sor - 1
+        return m, first, last
+
+    def covered(b, k, e):
+        m, first, _ = role(k)
+        ok = True
+        if first and k > 0:
+            ok = ok and prog[b, k - 1] >= min(ns, e + 1)
+        if b > 0:
+            ok = ok and prog[b - 1, k] >= min(ns, e + 63)
+        return ok
+
+    def window(b, k):
+        r0 = ROWS * b - k - 1
+        return r0 + qt, slice(r0 + rt, r0 + rt + LANES)
+
+    def load_global_pd(c, b, k, s):
+        """what the kernel's (du, dv) load instruction of step s returns: wave 0 lanes >= 1 <- previous group's plane,
+        lane 0 <- halo row of the band above; LDS-fed lanes load nothing (0)"""
+        m, first, _ = role(k)
+        g = k // group
+        v = np.zeros(LANES)
+        if first:
+            v[1:] = D[c, (g + 1) & 1, s + 1, b, :63]
+        if b > 0 and 0 <= s + 64 < npos_d:
+            v[0] = HALO[c, k, b - 1, s + 64]
+        return v
+
+    def load_slot(b, k, s):
+        q0, rows = window(b, k)
+        gg = lambda n: P[n][q0 + s, rows].copy()
+        z = lambda n: np.where(real, P[n][q0 + s, rows], 0.0)
+        return dict(phi=gg("phi"), xy=gg("xy"), a1=z("a1"), a2=z("a2"), b1=z("b1"), b2=z("b2"),
+                    duR=load_global_pd(0, b, k, s), dvR=load_global_pd(1, b, k, s))
+
+    class GT:
+        def __init__(self, b, k):
+            self.b, self.k, self.hi = b, k, -1      # hi: next half-iteration index (-1: prologue)
+            z = np.zeros(LANES)
+            self.duL, self.dvL, self.phiL, self.duC, self.dvC = z.copy(), z.copy(), z.copy(), z.copy(), z.copy()
+            self.slots = [None] * r
+
+    pending = [GT(b, k) for k in range(n_sor) for b in range(nb)]
+    while pending:
+        ran = False
+        for ti in rng.permutation(len(pending)):
+            t = pending[ti]
+            b, k = t.b, t.k
+            m, first, last = role(k)
+            g = k // group
+            if t.hi < 0:
+                if not covered(b, k, 2 * r):
+                    continue
+                t.duC, t.dvC = load_global_pd(0, b, k, -1), load_global_pd(1, b, k, -1)
+                for s in range(r):
+                    t.slots[s] = load_slot(b, k, s)
+                t.hi = 0
+                ran = True
+                break
+            i, sa = t.hi // 2, t.hi * half
+            if t.hi % 2 == 0 and i > 0 and not covered(b, k, (i + 2) * r):
+                continue
+            if not first and done[b, k - 1] < sa + half:           # the wave before has not written these steps yet
+                continue
+            if not last and sa + half > ring and taken[b, k] < sa + half - ring:  # ring slots still unread
+                continue
+            ran = True
+            lds = None
+            if not first:  # H blocks out of the ring of the wave before, cell lane - 1
+                lds = [(RING[0, k - 1, b, (sa + q) % ring].copy(), RING[1, k - 1, b, (sa + q) % ring].copy())
+                       for q in range(half)]
+            for q in range(half):
+                s = sa + q
+                c = t.slots[s % r]
+                duR, dvR = c["duR"].copy(), c["dvR"].copy()
+                if not first:
+                    duR[1:], dvR[1:] = lds[q][0][:63], lds[q][1][:63]
+                duU, dvU, phiU = shift_up(t.duL), shift_up(t.dvL), shift_up(t.phiL)
+                duD, dvD = shift_down(duR), shift_down(dvR)
+                s1 = t.phiL * t.duL
+                s2 = t.phiL * t.dvL
+                s1 = s1 + c["phi"] * duR
+                s2 = s2 + c["phi"] * dvR
+                s1 = s1 + phiU * duU
+                s2 = s2 + phiU * dvU
+                s1 = s1 + c["phi"] * duD
+                s2 = s2 + c["phi"] * dvD
+                s1 = s1 * nalpha
+                s2 = s2 * nalpha
+                s1 = s1 + c["xy"] * t.dvC
+                duN = om1 * t.duC + c["a1"] * (c["b1"] - s1)
+                s2 = s2 + c["xy"] * duN
+                dvN = om1 * t.dvC + c["a2"] * (c["b2"] - s2)
+                if last:
+                    D[0, g & 1, s + 1, b, :] = duN
+                    D[1, g & 1, s + 1, b, :] = dvN
+                else:
+                    RING[0, k, b, s % ring] = duN
+                    RING[1, k, b, s % ring] = dvN
+                if b + 1 < nb and s + 1 < npos_d:
+                    HALO[0, k, b, s + 1] = duN[62]
+                    HALO[1, k, b, s + 1] = dvN[62]
+                t.duL, t.dvL, t.phiL = duN, dvN, c["phi"]
+                t.duC, t.dvC = duR, dvR
+                t.slots[s % r] = load_slot(b, k, s + r)
+            if not first:
+                taken[b, k - 1] = sa + half
+            if not last:
+                done[b, k] = sa + half
+            prog[b, k] = max(prog[b, k], min(ns, sa))  # markers: the previous half is proven complete
+            t.hi += 1
+            if t.hi == 2 * n_iter:
+                prog[b, k] = ns
+                pending.pop(ti)
+            break
+        assert ran, "deadlock in the task graph"
+    kl = n_sor - 1
+    gl = kl // group
+    ii, jj = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    bb, cc = (ii + kl) // ROWS, 1 + (ii + kl) % ROWS
+    return D[0, gl & 1, jj + cc + 1, bb, cc], D[1, gl & 1, jj + cc + 1, bb, cc]

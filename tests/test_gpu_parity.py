@@ -263,3 +263,26 @@ def test_pyflow_dropin_entry_point(oracle):
         pyflow.coarse2fine_flow(None, b, 2)
     with pytest.raises(ValueError):
         pyflow.coarse2fine_flow(a.astype(np.float32), b.astype(np.float32), 2)
+
+
+@pytest.mark.parametrize("group", ["2", "4"])
+def test_grouped_sor_kernel_matches_oracle(oracle, group, monkeypatch):
+    """The opt-in grouped solver (PAPOF_SOR_GROUP: M sweeps of a band per workgroup, LDS hand-off; sor.hip
+    k_sor_group) must give the reference's bits too."""
+    from papteam_opticalflow_amd import Papof
+    monkeypatch.setenv("PAPOF_SOR_GROUP", group)
+    g = Papof(0)  # the environment is read when the handle is created
+    try:
+        for h, w, n_sor in [(70, 50, 4), (130, 37, 3), (1, 5, 3), (129, 3, 2), (341, 607, 42), (540, 960, 30),
+                            (200, 1000, 7), (63, 64, 1), (125, 66, 9)]:
+            planes = _sor_planes(h, w, h * 7 + w)
+            du, dv = g.sor(*planes, n_sor, mode=0)
+            eu, ev = oracle.sor(*planes, n_sor, mode=0)
+            assert np.array_equal(du, eu) and np.array_equal(dv, ev), (group, h, w, n_sor)
+        a, b = cases.load_pair("240")
+        got = g.coarse2fine_flow(a, b, 4)[:3]
+        want = oracle.coarse2fine_flow(a, b, 4)[:3]
+        for x, y in zip(got, want):
+            assert np.array_equal(x, y)
+    finally:
+        g.close()

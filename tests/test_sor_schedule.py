@@ -30,6 +30,21 @@ def test_wave_schedule_is_bit_exact(oracle, h, w, n_sor, chunk):
     assert np.array_equal(dv, ev)
 
 
+@pytest.mark.parametrize("h,w,n_sor,chunk,group,ring", [(70, 50, 5, 8, 4, 16), (130, 37, 6, 8, 2, 16), (64, 20, 9, 8, 4, 8),
+                                                         (1, 5, 3, 4, 4, 4), (129, 3, 4, 6, 4, 16), (42, 75, 7, 10, 4, 16),
+                                                         (190, 40, 4, 8, 3, 16)])
+def test_grouped_wave_schedule_is_bit_exact(oracle, h, w, n_sor, chunk, group, ring):
+    """M sweeps of a band per workgroup, handed from wave to wave through an LDS ring (k_sor_group)."""
+    alpha, omega = 0.012, 1.8
+    phi, imdxy, imdx2, imdy2, r1, r2 = _planes(h, w, h * 1000 + w + 1)
+    a1, a2 = sim.sor_coefficients(phi, imdx2, imdy2, alpha, omega)
+    du, dv = sim.simulate_grouped(phi, imdxy, a1, a2, r1, r2, n_sor, alpha, omega, r=chunk, group=group, ring=ring,
+                                  seed=h)
+    eu, ev = oracle.sor(phi, imdxy, imdx2, imdy2, r1, r2, n_sor, alpha=alpha, omega=omega, mode=0)
+    assert np.array_equal(du, eu)
+    assert np.array_equal(dv, ev)
+
+
 def test_skew_roundtrip():
     rng = np.random.default_rng(0)
     p = rng.standard_normal((150, 33))
