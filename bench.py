@@ -357,6 +357,23 @@ def main():
             for _ in range(3):
                 gpu.coarse2fine_flow(a, b, args.levels, P)
             out["pcie_inclusive_ms_per_pair"] = round((time.perf_counter() - th) / 3 * 1e3, 3)
+            try:  # the callers' side: uint8 frames in, and a video pushed frame by frame
+                import cases
+                a8, b8 = cases.load_frame_u8(args.res, 1), cases.load_frame_u8(args.res, 2)
+                gpu.coarse2fine_flow_u8(a8, b8, args.levels, P)
+                th = time.perf_counter()
+                for _ in range(3):
+                    gpu.coarse2fine_flow_u8(a8, b8, args.levels, P)
+                out["pcie_inclusive_u8_ms_per_pair"] = round((time.perf_counter() - th) / 3 * 1e3, 3)
+                gpu.seq_reset()
+                gpu.seq_push(a8, args.levels, P)
+                gpu.seq_push(b8, args.levels, P)
+                th = time.perf_counter()
+                for i in range(4):
+                    gpu.seq_push(a8 if i % 2 == 0 else b8, args.levels, P)
+                out["sequence_u8_ms_per_frame"] = round((time.perf_counter() - th) / 4 * 1e3, 3)
+            except Exception as e:  # noqa: BLE001 -- secondary figures only
+                out["callers_side_error"] = "%s: %s" % (type(e).__name__, e)
         if world == 1 and not args.no_cpu_baseline and not simulate:
             kind, dt = cpu_baseline(a, b, args.levels, sched, mode)
             out["cpu_baseline"] = {"value": round(h * w / 1e6 / dt, 5), "unit": "Mpix/s", "cores": 1, "kind": kind,

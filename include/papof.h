@@ -224,6 +224,23 @@ int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2
 int papof_stage_bicubic_warp(papof_handle* h, const double* im1, const double* im2, const double* vx,
                              const double* vy, int height, int width, int c, double* out);
 
+/* ---- the step after the path: the reference's 16-bit flow encoding,
+ * OpticalFlow::SaveOpticalFlow / LoadOpticalFlow (src/OpticalFlow.cpp:963-1015) with AssembleFlow / DissembleFlow
+ * (src/OpticalFlow.h:70-91): out[(i*width + j)*2 + {0,1}] = (unsigned short)((clamp(v{x,y}, -200, 200) + 200) * 160);
+ * back: (double)q / 160 - 200.  The file Image<unsigned short>::saveImage writes around it (src/Image.h:825-837:
+ * 16-byte type name, width, height, channels as int, one bool) is plain host I/O: papteam_opticalflow_amd.save_flow16. */
+int papof_flow_quantize16(papof_handle* h, const double* vx, const double* vy, int height, int width,
+                          unsigned short* out);
+int papof_flow_dequantize16(papof_handle* h, const unsigned short* q, int height, int width, double* vx,
+                            double* vy);
+
+/* Flow visualisation of the reference's caller, generateOutputFlowImageFile (Code/Serial/OpticalFlowCalculation.py:
+ * 143-162, disabled there at :137 and dependent on cv2): hue = direction, value = magnitude (min-max normalised),
+ * saturation 255, HSV -> BGR the way OpenCV's 8-bit conversion does; bgr is height*width*3 bytes, B first.
+ * PARITY UNPINNED: OpenCV is not installed in this environment and its cartToPolar uses an approximate atan2. */
+int papof_flow_to_bgr(papof_handle* h, const double* vx, const double* vy, int height, int width,
+                      unsigned char* bgr);
+
 /* ---- measurement hook for bench.py: time `reps` back-to-back SOR solves of `n_sor` sweeps on synthetic
  * coefficient planes already resident in HBM (SURVEY.md §8d micro-benchmark), with HIP events recorded
  * on the handle's stream.  Returns average milliseconds per solve in *ms_per_solve. */

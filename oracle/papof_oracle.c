@@ -644,6 +644,31 @@ void orc_bicubic_warp(const double* im1, const double* im2, const double* vx, co
     free(gxy);
 }
 
+/* OpticalFlow::SaveOpticalFlow (src/OpticalFlow.cpp:993-1003): clamp with the __max/__min templates of src/project.h:41-50
+ * (they return the first argument's type: double), shift, scale, convert to unsigned short (truncation). */
+void orc_flow_quantize16(const double* vx, const double* vy, int h, int w, unsigned short* q) {
+    const long n = (long)h * w;
+    for (long i = 0; i < n; i++) {
+        double a = vx[i], b = vy[i];
+        a = (a < -200) ? -200.0 : a; /* __max(f, -200) */
+        a = (a > 200) ? 200.0 : a;   /* __min(.., 200)  */
+        b = (b < -200) ? -200.0 : b;
+        b = (b > 200) ? 200.0 : b;
+        q[i * 2] = (unsigned short)((a + 200) * 160);
+        q[i * 2 + 1] = (unsigned short)((b + 200) * 160);
+    }
+}
+
+/* OpticalFlow::LoadOpticalFlow (src/OpticalFlow.cpp:963-976) + DissembleFlow (src/OpticalFlow.h:80-91). */
+void orc_flow_dequantize16(const unsigned short* q, int h, int w, double* vx, double* vy) {
+    const long n = (long)h * w;
+    for (long i = 0; i < n; i++) {
+        vx[i] = (double)q[i * 2] / 160 - 200;
+        vy[i] = (double)q[i * 2 + 1] / 160 - 200;
+    }
+}
+
+
 /* ---------------------------------------------------------------------------------------------
  * OpticalFlow::Coarse2FineFlow, src/OpticalFlow.cpp:735-903.
  * ------------------------------------------------------------------------------------------- */

@@ -246,4 +246,24 @@ int ref_bicubic_warp(const double* im1, const double* im2, const double* vx, con
     return 0;
 }
 
+// The reference's own 16-bit flow file: AssembleFlow (src/OpticalFlow.h:70-79) + SaveOpticalFlow (src/OpticalFlow.cpp:993-1003),
+// and back: LoadOpticalFlow (:963-976) + DissembleFlow (src/OpticalFlow.h:80-91).
+int ref_flow_save16(const double* vx, const double* vy, int h, int w, const char* path) {
+    DImage x(w, h), y(w, h), flow;
+    std::memcpy(x.data(), vx, sizeof(double) * (size_t)h * w);
+    std::memcpy(y.data(), vy, sizeof(double) * (size_t)h * w);
+    OpticalFlow::AssembleFlow(x, y, flow);
+    return OpticalFlow::SaveOpticalFlow(flow, path) ? 0 : -1;
+}
+
+int ref_flow_load16(const char* path, int h, int w, double* vx, double* vy) {
+    DImage flow, x, y;
+    if (!OpticalFlow::LoadOpticalFlow(path, flow)) return -1;
+    if (flow.width() != w || flow.height() != h || flow.nchannels() != 2) return -2;
+    OpticalFlow::DissembleFlow(flow, x, y);
+    std::memcpy(vx, x.data(), sizeof(double) * (size_t)h * w);
+    std::memcpy(vy, y.data(), sizeof(double) * (size_t)h * w);
+    return 0;
+}
+
 }  // extern "C"

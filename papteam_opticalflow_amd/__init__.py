@@ -83,3 +83,33 @@ class FlowSequence:
 
     def close(self):
         self.gpu.close()
+
+
+# ---- the reference's 16-bit flow file (OpticalFlow::SaveOpticalFlow / LoadOpticalFlow, src/OpticalFlow.cpp:963-1015) ----
+_FLOW16_HEADER = 29  # Image<unsigned short>::saveImage (src/Image.h:825-837): char type[16], int w, int h, int c, bool
+
+
+def save_flow16(path, vx, vy):
+    """Write (vx, vy) as the reference's SaveOpticalFlow does: the quantisation runs on the GPU
+    (papof_flow_quantize16), the 29-byte header is Image<unsigned short>::saveImage's (type name `t` =
+    typeid(unsigned short).name(); the reference leaves the rest of the 16 bytes uninitialised, written as zeros here)."""
+    import struct
+    q = _handle().flow_quantize16(vx, vy)
+    h, w, _ = q.shape
+    with open(path, "wb") as f:
+        f.write(b"t".ljust(16, b"\0") + struct.pack("<iii?", w, h, 2, False))
+        f.write(q.tobytes())
+
+
+def load_flow16(path):
+    """Read a file written by the reference's SaveOpticalFlow (or save_flow16); returns (vx, vy) float64."""
+    import struct
+    import numpy as np
+    raw = open(path, "rb").read()
+    if len(raw) < _FLOW16_HEADER or raw[:2] != b"t\0":
+        raise ValueError("not an Image<unsigned short> file")
+    w, h, c, _deriv = struct.unpack("<iii?", raw[16:_FLOW16_HEADER])
+    if c != 2 or len(raw) != _FLOW16_HEADER + 2 * w * h * c:
+        raise ValueError("not a 2-channel flow file")
+    q = np.frombuffer(raw, dtype=np.uint16, offset=_FLOW16_HEADER).reshape(h, w, 2)
+    return _handle().flow_dequantize16(q)

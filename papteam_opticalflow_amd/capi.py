@@ -46,7 +46,8 @@ SYMBOLS = [
     "papof_stage_bicubic_warp", "papof_bench_sor", "papof_flow_u8", "papof_flow_device_u8", "papof_seq_reset",
     "papof_seq_push", "papof_seq_push_u8", "papof_seq_push_device", "papof_tiles_grid", "papof_tiles_rect",
     "papof_tiles_halo_message", "papof_tiles_unique_id", "papof_tiles_create", "papof_tiles_create_local",
-    "papof_tiles_flow_device", "papof_tiles_stats", "papof_tiles_destroy",
+    "papof_tiles_flow_device", "papof_tiles_stats", "papof_tiles_destroy", "papof_flow_quantize16",
+    "papof_flow_dequantize16", "papof_flow_to_bgr",
 ]
 
 
@@ -98,6 +99,9 @@ def load():
     L.papof_tiles_stats.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_size_t)]
     L.papof_tiles_destroy.argtypes = [c_void_p]
     L.papof_tiles_destroy.restype = None
+    L.papof_flow_quantize16.argtypes = [c_void_p, _D, _D, c_int, c_int, c_void_p]
+    L.papof_flow_dequantize16.argtypes = [c_void_p, c_void_p, c_int, c_int, _D, _D]
+    L.papof_flow_to_bgr.argtypes = [c_void_p, _D, _D, c_int, c_int, c_void_p]
     L.papof_dev_alloc.argtypes = [c_void_p, ctypes.c_size_t, ctypes.POINTER(c_void_p)]
     L.papof_dev_free.argtypes = [c_void_p, c_void_p]
     L.papof_dev_upload.argtypes = [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]
@@ -377,6 +381,33 @@ class Papof:
         out = np.zeros_like(im1)
         _chk(self.L.papof_stage_bicubic_warp(self.h, _p(im1), _p(im2), _p(vx), _p(vy), h, w, c, _p(out)),
              "papof_stage_bicubic_warp")
+        return out
+
+    def flow_quantize16(self, vx, vy):
+        vx, vy = _c(vx, 2), _c(vy, 2)
+        h, w = vx.shape
+        q = np.zeros((h, w, 2), dtype=np.uint16)
+        _chk(self.L.papof_flow_quantize16(self.h, _p(vx), _p(vy), h, w, q.ctypes.data_as(c_void_p)),
+             "papof_flow_quantize16")
+        return q
+
+    def flow_dequantize16(self, q):
+        q = np.ascontiguousarray(q, dtype=np.uint16)
+        if q.ndim != 3 or q.shape[2] != 2:
+            raise ValueError("expected an H x W x 2 uint16 array, got %r" % (q.shape,))
+        h, w, _ = q.shape
+        vx, vy = np.zeros((h, w)), np.zeros((h, w))
+        _chk(self.L.papof_flow_dequantize16(self.h, q.ctypes.data_as(c_void_p), h, w, _p(vx), _p(vy)),
+             "papof_flow_dequantize16")
+        return vx, vy
+
+    def flow_to_bgr(self, vx, vy):
+        """uint8 H x W x 3 (B, G, R) visualisation of a flow field: generateOutputFlowImageFile of the reference's
+        caller (OpticalFlowCalculation.py:143-162) without cv2; parity unpinned (see include/papof.h)."""
+        vx, vy = _c(vx, 2), _c(vy, 2)
+        h, w = vx.shape
+        out = np.zeros((h, w, 3), dtype=np.uint8)
+        _chk(self.L.papof_flow_to_bgr(self.h, _p(vx), _p(vy), h, w, out.ctypes.data_as(c_void_p)), "papof_flow_to_bgr")
         return out
 
     def bench_sor(self, h, w, n_sor, mode=SOR_EXACT, reps=5, seed=2):

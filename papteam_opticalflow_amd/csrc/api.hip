@@ -1155,6 +1155,57 @@ int papof_stage_bicubic_warp(papof_handle* h, const double* im1, const double* i
     return PAPOF_OK;
 }
 
+int papof_flow_quantize16(papof_handle* h, const double* vx, const double* vy, int height, int width,
+                          unsigned short* out) {
+    if (!h || !vx || !vy || !out || height < 1 || width < 1) return PAPOF_EINVAL;
+    const size_t n = (size_t)height * width;
+    Scope S(h, n * (2 * sizeof(double) + 2 * sizeof(unsigned short)) + 4096);
+    PAPOF_TRY(S.rc);
+    double* a = S.up_planar(vx, height, width, 1);
+    double* b = S.up_planar(vy, height, width, 1);
+    unsigned short* q = reinterpret_cast<unsigned short*>(S.dev((n * 2 * sizeof(unsigned short) + 7) / 8));
+    PAPOF_TRY(S.rc);
+    PAPOF_TRY(flow_quantize16(h, a, b, q, n));
+    PAPOF_HIP(hipMemcpyAsync(out, q, n * 2 * sizeof(unsigned short), hipMemcpyDeviceToHost, h->stream));
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    return PAPOF_OK;
+}
+
+int papof_flow_dequantize16(papof_handle* h, const unsigned short* q, int height, int width, double* vx,
+                            double* vy) {
+    if (!h || !q || !vx || !vy || height < 1 || width < 1) return PAPOF_EINVAL;
+    const size_t n = (size_t)height * width;
+    Scope S(h, n * (2 * sizeof(double) + 2 * sizeof(unsigned short)) + 4096);
+    PAPOF_TRY(S.rc);
+    unsigned short* dq = reinterpret_cast<unsigned short*>(S.dev((n * 2 * sizeof(unsigned short) + 7) / 8));
+    double* a = S.dev(n);
+    double* b = S.dev(n);
+    PAPOF_TRY(S.rc);
+    PAPOF_HIP(hipMemcpyAsync(dq, q, n * 2 * sizeof(unsigned short), hipMemcpyHostToDevice, h->stream));
+    PAPOF_TRY(flow_dequantize16(h, dq, a, b, n));
+    PAPOF_HIP(hipMemcpyAsync(vx, a, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    PAPOF_HIP(hipMemcpyAsync(vy, b, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    return PAPOF_OK;
+}
+
+int papof_flow_to_bgr(papof_handle* h, const double* vx, const double* vy, int height, int width,
+                      unsigned char* bgr) {
+    if (!h || !vx || !vy || !bgr || height < 1 || width < 1) return PAPOF_EINVAL;
+    const size_t n = (size_t)height * width;
+    Scope S(h, n * (2 * sizeof(double) + 3) + 16384);
+    PAPOF_TRY(S.rc);
+    double* a = S.up_planar(vx, height, width, 1);
+    double* b = S.up_planar(vy, height, width, 1);
+    double* partial = S.dev(512);
+    unsigned char* out = reinterpret_cast<unsigned char*>(S.dev((n * 3 + 7) / 8));
+    PAPOF_TRY(S.rc);
+    PAPOF_TRY(flow_to_bgr(h, a, b, n, partial, out));
+    PAPOF_HIP(hipMemcpyAsync(bgr, out, n * 3, hipMemcpyDeviceToHost, h->stream));
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    return PAPOF_OK;
+}
+
 // SOR micro-benchmark on synthetic planes resident in HBM: phi~U(0.5,50), imdx2/imdy2~U(0,.05),
 // imdxy~U(-.02,.02), rhs~U(-.01,.01); alpha .012, omega 1.8.
 int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_mode, int reps, unsigned seed,

@@ -157,7 +157,7 @@ struct papof_handle {
     size_t pin_bytes = 0;
     int host_threads = 4;            // threads used to move pageable user buffers to / from the pinned buffers
     bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
-    int sor_depth = 10;              // software-pipeline depth R (steps) of the exact-order SOR kernel
+    int sor_depth = 0;               // software-pipeline depth R (steps) of the exact-order SOR kernel; 0 = by level size
     unsigned long long* sor_dbg = nullptr;  // device buffer for per-task wait statistics (PAPOF_SOR_DBG)
     int sor_group = 0;               // consecutive sweeps of a band per workgroup: 1, 2 or 4; 0 = by problem size
     // second stream for everything that does not depend on the flow (pyramids, features, smoothed frame 1 of every
@@ -204,6 +204,9 @@ int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, 
 int bicubic_warp(papof_handle* h, const double* im1, const double* im2, const double* gx, const double* gy,
                  const double* gxy, const double* vx, const double* vy, double* out_hwc, int H, int W, int C,
                  const Rect* rc = nullptr);
+int flow_quantize16(papof_handle* h, const double* vx, const double* vy, unsigned short* q, size_t n);
+int flow_dequantize16(papof_handle* h, const unsigned short* q, double* vx, double* vy, size_t n);
+int flow_to_bgr(papof_handle* h, const double* vx, const double* vy, size_t n, double* partial, unsigned char* bgr);
 int update_flow(papof_handle* h, const SorPlanes& sp, double* u, double* v, int H, int W, const Rect& r);
 int sor_prep(papof_handle* h, const double* phi, const double* imdxy, const double* imdx2, const double* imdy2,
              const double* rhs1, const double* rhs2, int H, int W, double alpha, double omega, const SorPlanes& out);

@@ -616,6 +616,93 @@ __global__ void k_bicubic(const double* __restrict__ im1, const double* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The reference's 16-bit flow encoding, OpticalFlow::SaveOpticalFlow / LoadOpticalFlow (src/OpticalFlow.cpp:963-1015):
+// q = (unsigned short)((min(max(f, -200), 200) + 200) * 160), (vx, vy) interleaved per pixel (AssembleFlow,
+// src/OpticalFlow.h:70-79); back: f = (double)q / 160 - 200.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_flow_quantize16(const double* __restrict__ vx, const double* __restrict__ vy,
+                                  unsigned short* __restrict__ q, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = vx[i], b = vy[i];
+    a = (a < -200) ? -200.0 : a;
+    a = (a > 200) ? 200.0 : a;
+    b = (b < -200) ? -200.0 : b;
+    b = (b > 200) ? 200.0 : b;
+    q[i * 2] = (unsigned short)((a + 200) * 160);
+    q[i * 2 + 1] = (unsigned short)((b + 200) * 160);
+}
+
+__global__ void k_flow_dequantize16(const unsigned short* __restrict__ q, double* __restrict__ vx,
+                                    double* __restrict__ vy, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    vx[i] = (double)q[i * 2] / 160 - 200;
+    vy[i] = (double)q[i * 2 + 1] / 160 - 200;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Flow visualisation of the reference's caller, generateOutputFlowImageFile (Code/Serial/OpticalFlowCalculation.py:
+// 143-162): hue = angle / 2 in degrees, saturation 255, value = magnitude min-max normalised to 0..255, converted
+// HSV -> BGR as OpenCV's 8-bit path does (float32: h * 6/180, sector table, round to nearest).  PARITY UNPINNED: cv2 is
+// not installed here, and cv2.cartToPolar uses a polynomial atan2 (~0.3 degrees), so a hue may differ by one step
+// from an OpenCV run; this kernel uses the exact atan2.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_flow_mag_minmax(const double* __restrict__ vx, const double* __restrict__ vy, size_t n,
+                                  double* __restrict__ partial) {  // partial[2*block] = min, [2*block+1] = max
+    __shared__ double smin[256], smax[256];
+    double lo = INFINITY, hi = -INFINITY;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double m = sqrt(vx[i] * vx[i] + vy[i] * vy[i]);
+        lo = m < lo ? m : lo;
+        hi = m > hi ? m : hi;
+    }
+    smin[threadIdx.x] = lo;
+    smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + s]);
+            smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = smin[0];
+        partial[2 * blockIdx.x + 1] = smax[0];
+    }
+}
+
+__global__ void k_flow_bgr(const double* __restrict__ vx, const double* __restrict__ vy, size_t n,
+                           const double* __restrict__ partial, int nblocks, unsigned char* __restrict__ bgr) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double lo = INFINITY, hi = -INFINITY;
+    for (int b = 0; b < nblocks; b++) {
+        lo = fmin(lo, partial[2 * b]);
+        hi = fmax(hi, partial[2 * b + 1]);
+    }
+    const double x = vx[i], y = vy[i];
+    const double mag = sqrt(x * x + y * y);
+    double ang = atan2(y, x);  // cv2.cartToPolar: radians in [0, 2 pi)
+    if (ang < 0) ang += 2 * M_PI;
+    const unsigned char H = (unsigned char)(int)(ang * 180 / M_PI / 2);
+    const double scale = hi > lo ? 255.0 / (hi - lo) : 0.0;  // cv2.normalize(..., 0, 255, NORM_MINMAX)
+    const unsigned char V = (unsigned char)(int)((mag - lo) * scale);
+    // OpenCV HSV2BGR, 8-bit, S = 255
+    const float v = V * (1.f / 255.f);
+    float h = H * (6.f / 180.f);
+    int sector = (int)floorf(h);
+    h -= sector;
+    sector = ((sector % 6) + 6) % 6;
+    const float tab[4] = {v, 0.f, v * (1.f - h), v * h};
+    const int sd[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    bgr[i * 3] = (unsigned char)(int)rintf(tab[sd[sector][0]] * 255.f);
+    bgr[i * 3 + 1] = (unsigned char)(int)rintf(tab[sd[sector][1]] * 255.f);
+    bgr[i * 3 + 2] = (unsigned char)(int)rintf(tab[sd[sector][2]] * 255.f);
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -805,6 +892,31 @@ int update_flow(papof_handle* h, const SorPlanes& sp, double* u, double* v, int 
     if (r.empty()) return PAPOF_OK;
     hipLaunchKernelGGL(k_update_warp, grid2d(r), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, u, v, nullptr, nullptr, nullptr,
                        H, W, 0, r, 0);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int flow_quantize16(papof_handle* h, const double* vx, const double* vy, unsigned short* q, size_t n) {
+    if (!n) return PAPOF_OK;
+    hipLaunchKernelGGL(k_flow_quantize16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, vx, vy, q, n);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int flow_dequantize16(papof_handle* h, const unsigned short* q, double* vx, double* vy, size_t n) {
+    if (!n) return PAPOF_OK;
+    hipLaunchKernelGGL(k_flow_dequantize16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, q, vx, vy, n);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int flow_to_bgr(papof_handle* h, const double* vx, const double* vy, size_t n, double* partial /* 2 * 256 */,
+                unsigned char* bgr) {
+    if (!n) return PAPOF_OK;
+    const int nblocks = 256;
+    hipLaunchKernelGGL(k_flow_mag_minmax, dim3(nblocks), dim3(256), 0, h->stream, vx, vy, n, partial);
+    hipLaunchKernelGGL(k_flow_bgr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, vx, vy, n, partial,
+                       nblocks, bgr);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }

@@ -143,6 +143,22 @@ class OracleLib:
         self.L.orc_bicubic_warp(_p(im1), _p(im2), _p(vx), _p(vy), h, w, c, _p(out))
         return out
 
+    def flow_quantize16(self, vx, vy):
+        vx, vy = _c(vx), _c(vy)
+        h, w = vx.shape
+        q = np.zeros((h, w, 2), dtype=np.uint16)
+        self.L.orc_flow_quantize16.argtypes = [_D, _D, c_int, c_int, ctypes.c_void_p]
+        self.L.orc_flow_quantize16(_p(vx), _p(vy), h, w, q.ctypes.data_as(ctypes.c_void_p))
+        return q
+
+    def flow_dequantize16(self, q):
+        q = np.ascontiguousarray(q, dtype=np.uint16)
+        h, w, _ = q.shape
+        vx, vy = np.zeros((h, w)), np.zeros((h, w))
+        self.L.orc_flow_dequantize16.argtypes = [ctypes.c_void_p, c_int, c_int, _D, _D]
+        self.L.orc_flow_dequantize16(q.ctypes.data_as(ctypes.c_void_p), h, w, _p(vx), _p(vy))
+        return vx, vy
+
     def linear_system(self, imdx, imdy, imdt, u, v, du=None, dv=None, alpha=0.012, lappara=None):
         imdx, imdy, imdt, u, v = _c(imdx), _c(imdy), _c(imdt), _c(u), _c(v)
         h, w, c = imdx.shape
@@ -286,6 +302,37 @@ class RefLib:
         out = np.zeros_like(im1)
         self.L.ref_bicubic_warp(_p(im1), _p(im2), _p(vx), _p(vy), h, w, c, _p(out))
         return out
+
+    def flow_file16(self, vx, vy):
+        """bytes of the file the reference's SaveOpticalFlow writes (header: 16-byte type name, 3 ints, 1 bool)"""
+        import tempfile
+        vx, vy = _c(vx), _c(vy)
+        h, w = vx.shape
+        self.L.ref_flow_save16.argtypes = [_D, _D, c_int, c_int, ctypes.c_char_p]
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "flow.bin")
+            assert self.L.ref_flow_save16(_p(vx), _p(vy), h, w, path.encode()) == 0
+            return open(path, "rb").read()
+
+    def flow_quantize16(self, vx, vy):
+        h, w = np.shape(vx)
+        raw = self.flow_file16(vx, vy)
+        return np.frombuffer(raw[29:], dtype=np.uint16).reshape(h, w, 2).copy()
+
+    def flow_dequantize16(self, q):
+        """through the reference's LoadOpticalFlow, from a file with the reference's own header layout"""
+        import struct
+        import tempfile
+        q = np.ascontiguousarray(q, dtype=np.uint16)
+        h, w, _ = q.shape
+        vx, vy = np.zeros((h, w)), np.zeros((h, w))
+        self.L.ref_flow_load16.argtypes = [ctypes.c_char_p, c_int, c_int, _D, _D]
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "flow.bin")
+            with open(path, "wb") as f:
+                f.write(b"t".ljust(16, b"\0") + struct.pack("<iii?", w, h, 2, False) + q.tobytes())
+            assert self.L.ref_flow_load16(path.encode(), h, w, _p(vx), _p(vy)) == 0
+        return vx, vy
 
     def smoothflow_sor(self, im1, im2, warp, u, v, alpha, n_outer, n_inner, n_sor, omega=1.8, mode=0):
         assert omega == 1.8 and mode == 0, "the reference hard-codes omega and the sweep order"

@@ -176,6 +176,19 @@ def stage_smoothflow(lib):
             "tiny_u": u3, "tiny_v": v3}
 
 
+def stage_flow16(lib):
+    """The reference's 16-bit flow encoding (OpticalFlow::SaveOpticalFlow / LoadOpticalFlow, src/OpticalFlow.cpp:963-1015):
+    clamp at +-200, the truncating conversion, and the way back."""
+    rng = np.random.default_rng(11)
+    vx = smooth_field(rng, 67, 93, 60.0)
+    vy = smooth_field(rng, 67, 93, 120.0)
+    vx[0, :8] = [250, -250, 200, -200, 199.99999, -199.99999, 0.003, -0.003]
+    vy[0, :8] = [1e9, -1e9, 0.0, -0.0, 1 / 160.0, -1 / 160.0, 0.00624, 123.456]
+    q = lib.flow_quantize16(vx, vy)
+    dx, dy = lib.flow_dequantize16(q)
+    return {"q": q.astype(np.float64), "vx": dx, "vy": dy}
+
+
 CASES = {
     "e2e_240_L1": _e2e("240", 1),
     "e2e_240_L2": _e2e("240", 2),
@@ -201,6 +214,7 @@ CASES = {
     "stage_getdxs": stage_getdxs,
     "stage_laplacian": stage_laplacian,
     "stage_smoothflow": stage_smoothflow,
+    "stage_flow16": stage_flow16,
 }
 
 # cases whose oracle run takes > ~15 s on one core; exercised by the CPU suite only when PAPOF_SLOW=1

@@ -39,7 +39,7 @@ def _cmp(name, got, want, tol):
 
 
 STAGES = ["stage_pyramid", "stage_gaussian", "stage_resize", "stage_im2feature", "stage_warp", "stage_getdxs",
-          "stage_laplacian", "stage_smoothflow"]  # stage_smoothflow includes nInner = 2 (src/OpticalFlow.cpp:300-304)
+          "stage_laplacian", "stage_smoothflow", "stage_flow16"]  # stage_smoothflow includes nInner = 2 (src/OpticalFlow.cpp:300-304)
 
 
 @pytest.mark.parametrize("case", STAGES)
@@ -286,3 +286,49 @@ def test_grouped_sor_kernel_matches_oracle(oracle, group, monkeypatch):
             assert np.array_equal(x, y)
     finally:
         g.close()
+
+
+def test_flow16_file_roundtrip_and_reference_layout(gpu, oracle, tmp_path):
+    """save_flow16 / load_flow16: the reference's SaveOpticalFlow file layout (src/Image.h:825-837) around the GPU
+    quantisation; the payload must be the oracle's bytes, and reading back gives the dequantised flow."""
+    import struct
+    from papteam_opticalflow_amd import load_flow16, save_flow16
+    a, b = cases.load_pair("240")
+    vx, vy, _, _ = gpu.coarse2fine_flow(a, b, 3)
+    p = str(tmp_path / "flow.bin")
+    save_flow16(p, vx, vy)
+    raw = open(p, "rb").read()
+    assert raw[:2] == b"t\0" and struct.unpack("<iii?", raw[16:29]) == (240, 135, 2, False)
+    q = oracle.flow_quantize16(vx, vy)
+    assert raw[29:] == q.tobytes()
+    lx, ly = load_flow16(p)
+    ox, oy = oracle.flow_dequantize16(q)
+    assert np.array_equal(lx, ox) and np.array_equal(ly, oy)
+    assert np.abs(lx - vx).max() <= 1 / 160.0
+
+
+def test_flow_visualisation_matches_its_numpy_restatement(gpu):
+    """generateOutputFlowImageFile (OpticalFlowCalculation.py:143-162) without cv2.  PARITY UNPINNED against OpenCV
+    (not installed; its cartToPolar is approximate): checked against a numpy restatement of the same formulas with
+    one hue step / one grey level of slack, plus the properties any implementation must have."""
+    rng = np.random.default_rng(3)
+    vx = cases.smooth_field(rng, 70, 90, 3.0)
+    vy = cases.smooth_field(rng, 70, 90, 2.0)
+    got = gpu.flow_to_bgr(vx, vy).astype(np.int32)
+    mag = np.sqrt(vx * vx + vy * vy)
+    ang = np.mod(np.arctan2(vy, vx), 2 * np.pi)
+    H = (ang * 180 / np.pi / 2).astype(np.uint8).astype(np.float32)
+    V = ((mag - mag.min()) * (255.0 / (mag.max() - mag.min()))).astype(np.uint8).astype(np.float32) / np.float32(255)
+    hh = H * np.float32(6.0 / 180.0)
+    sec = np.floor(hh).astype(int)
+    f = (hh - sec).astype(np.float32)
+    tab = np.stack([V, np.zeros_like(V), V * (1 - f), V * f], axis=-1)
+    sd = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])[sec % 6]
+    want = np.rint(np.take_along_axis(tab, sd, axis=-1) * 255).astype(np.int32)
+    assert np.abs(got - want).max() <= 9 and (got != want).mean() < 0.02  # one hue step moves a channel by <= 255 * 6 / 180
+    z = gpu.flow_to_bgr(np.zeros((4, 5)), np.zeros((4, 5)))
+    assert not z.any()  # no motion: black
+    e = gpu.flow_to_bgr(np.array([[1.0, 0.0, -1.0, 0.0]]), np.array([[0.0, 1.0, 0.0, -1.0]]))
+    assert e.shape == (1, 4, 3) and not e.any()  # equal magnitudes normalise to value 0
+    r = gpu.flow_to_bgr(np.array([[2.0, 0.0]]), np.array([[0.0, 0.0]]))
+    assert tuple(r[0, 0]) == (0, 0, 255) and not r[0, 1].any()  # rightward motion: hue 0 = red, full value
