@@ -576,9 +576,9 @@ __device__ __forceinline__ void g_step(const GroupArgs& A, const Task& T, const 
     __builtin_amdgcn_raw_buffer_store_b128(out, T.rd, L.hs + (unsigned)s * 16u, 0, kAuxSc1);  // lane 62 -> halo row
     S.duL = duN;
     S.dvL = dvN;
-    S.phiL = phiC;
-    S.duC = duR;
-    S.dvC = dvR;
+    S.phiL = moved(phiC);  // see moved(): no slot register may stay live across its refill
+    S.duC = moved(duR);
+    S.dvC = moved(dvR);
     asm volatile("" ::: "memory");
     g_load_coef<R, t>(T, L, s + R, c);
     g_load_unknowns<R, t>(T, L, s + R, c);
@@ -617,17 +617,13 @@ struct GFill<R, -1> {
 
 // LDS progress words: the LDS unit executes a wave's operations in order, so cells written before a word are visible to
 // whoever has seen the word; an explicit lgkmcnt wait keeps the issue order.  Bounded like every other wait.
-__device__ __forceinline__ bool lds_wait_ge(const GroupArgs& A, lds_word* p, unsigned need) {
+__device__ __forceinline__ bool lds_wait_ge(lds_word* p, unsigned need, lds_word* group_abort) {
+    // LDS accesses only: a vector-memory instruction inside this loop would make the loop exit a join of different
+    // vmcnt states, and the compiler would drain the operand pipeline (`s_waitcnt vmcnt(0)`) after every wait
     unsigned spins = 0;
     while (*p < need) {
         __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 1023u) == 0u) {
-            if (__hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            if (spins > (kSpinLimit << 3)) {
-                __hip_atomic_store(A.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
+        if ((++spins & 255u) == 0u && (*group_abort != 0u || spins > (kSpinLimit << 3))) return false;
     }
     asm volatile("" ::: "memory");
     return true;
@@ -636,7 +632,8 @@ __device__ __forceinline__ bool lds_wait_ge(const GroupArgs& A, lds_word* p, uns
 struct GWaveCtx {  // wave-uniform
     lds_u32x4 *ring_in, *ring_out;
     lds_word *done_in, *taken_in, *done_out, *taken_out;
-    int task;  // k * nb + b (diagnostics)
+    lds_word* group_abort;  // set by a wave of the group that gives up, so that its siblings stop waiting for it
+    int task;               // k * nb + b (diagnostics)
     unsigned* my_prog;
     Deps D;
     int ns, n_iter;
@@ -651,6 +648,11 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
     ExactArgs X;  // the waiting helpers only look at these
     X.abort = A.abort;
     X.ns = ns;
+    // giving up (abort seen, or a bounded wait expired): tell the siblings, and the host through the abort word
+    const auto give_up = [&]() {
+        *W.group_abort = 1u;
+        __hip_atomic_store(A.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     State S;
     S.duL = S.dvL = S.phiL = 0.0;
     GSlots<R> c;
@@ -663,7 +665,7 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
     const bool dbg = A.dbg != nullptr;
     GFill<R, R - 1>::coef(T, L, c);
     Polls pl = poll(W.D);
-    if (!wait_covered(X, pl, W.D, 2 * R)) return;
+    if (!wait_covered(X, pl, W.D, 2 * R)) return give_up();
     if (dbg) t_start = __builtin_amdgcn_s_memtime();
     {  // centre of the first cells: position 0 (zero; LDS-fed lanes: the same zero), lane 0: halo position 63
         const unsigned first = L.pd == kOob ? kOob : L.pd - L.pd_step;
@@ -677,13 +679,14 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
     const auto half_begin = [&](int sa) -> bool {
         if (FROM_LDS) {
             const unsigned long long ta = dbg ? __builtin_amdgcn_s_memtime() : 0;
-            if (!lds_wait_ge(A, W.done_in, (unsigned)(sa + H))) return false;
+            if (!lds_wait_ge(W.done_in, (unsigned)(sa + H), W.group_abort)) return false;
             if (dbg) t_in += __builtin_amdgcn_s_memtime() - ta;
 #pragma unroll
             for (int q = 0; q < H; q++) lpd[q] = W.ring_in[((sa + q) & (kRing - 1)) * kLanes + lcell];
         }
         const unsigned long long tb = dbg ? __builtin_amdgcn_s_memtime() : 0;
-        if (TO_LDS && sa + H > kRing && !lds_wait_ge(A, W.taken_out, (unsigned)(sa + H - kRing))) return false;
+        if (TO_LDS && sa + H > kRing && !lds_wait_ge(W.taken_out, (unsigned)(sa + H - kRing), W.group_abort))
+            return false;
         if (dbg) t_out += __builtin_amdgcn_s_memtime() - tb;
         return true;
     };
@@ -701,25 +704,25 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
     unsigned mb = 0u;
     for (int i = 0; i < W.n_iter; ++i) {
         const unsigned long long tc = dbg ? __builtin_amdgcn_s_memtime() : 0;
-        if (i > 0 && !wait_covered(X, pl, W.D, (i + 2) * R)) return;
+        if (i > 0 && !wait_covered(X, pl, W.D, (i + 2) * R)) return give_up();
         if (dbg) t_cov += __builtin_amdgcn_s_memtime() - tc;
         const Polls pn = poll(W.D);
         const int s0 = i * R;
-        if (!half_begin(s0)) return;
+        if (!half_begin(s0)) return give_up();
         GSeg<R, 0, DM, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
         if (i > 0) {
             asm volatile("" ::"v"(mb), "v"(S.duL), "v"(S.dvL) : "memory");
-            if (mb != 0u) return;
+            if (mb != 0u) return give_up();
             if (lane == 0)
                 __hip_atomic_store(W.my_prog, (unsigned)min(ns, s0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         GSeg<R, DM, H, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
         const unsigned ma = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         half_end(s0);
-        if (!half_begin(s0 + H)) return;
+        if (!half_begin(s0 + H)) return give_up();
         GSeg<R, H, H + DM, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
         asm volatile("" ::"v"(ma), "v"(S.duL), "v"(S.dvL) : "memory");
-        if (ma != 0u) return;
+        if (ma != 0u) return give_up();
         if (lane == 0)
             __hip_atomic_store(W.my_prog, (unsigned)min(ns, s0 + H), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         GSeg<R, H + DM, R, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
@@ -744,11 +747,13 @@ __global__ __launch_bounds__(64 * M) void k_sor_group(GroupArgs A) {
     __shared__ u32x4 ring[(M > 1 ? M - 1 : 1) * kRing * kLanes];
     __shared__ unsigned lds_done[M];   // [m]: steps of wave m whose cells are in its ring
     __shared__ unsigned lds_taken[M];  // [m]: steps of ring m the wave after has read
+    __shared__ unsigned lds_abort;
     const unsigned lane = threadIdx.x & 63u;
     const int m = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform by construction
     if (lane == 0) {
         lds_done[m] = 0u;
         lds_taken[m] = 0u;
+        if (m == 0) lds_abort = 0u;
     }
     __syncthreads();  // the only barrier: every wave is still here
     int g, b;
@@ -773,6 +778,7 @@ __global__ __launch_bounds__(64 * M) void k_sor_group(GroupArgs A) {
     W.taken_in = (lds_word*)&lds_taken[m > 0 ? m - 1 : 0];
     W.done_out = (lds_word*)&lds_done[m];
     W.taken_out = (lds_word*)&lds_taken[m];
+    W.group_abort = (lds_word*)&lds_abort;
     W.task = k * A.nb + b;
     W.ns = A.ns;
     W.n_iter = (A.ns + R - 1) / R;
