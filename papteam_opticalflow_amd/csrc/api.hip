@@ -513,7 +513,7 @@ int papof_create(int device, papof_handle** out) {
     if (const char* cs = std::getenv("PAPOF_HOST_THREADS")) h->host_threads = std::max(1, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_SOR_DEPTH")) h->sor_depth = std::max(4, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_SOR_GROUP")) h->sor_group = std::max(1, std::atoi(cs));
-    if (const char* cs = std::getenv("PAPOF_SOR_XCD")) h->sor_xcd_affine = std::atoi(cs) != 0;
+    if (const char* cs = std::getenv("PAPOF_SOR_XCD")) h->sor_xcd_affine = std::atoi(cs);
     int rc = sor_probe_dpp(h);
     if (rc != PAPOF_OK) {
         papof_destroy(h);

@@ -165,7 +165,7 @@ struct papof_handle {
     hipStream_t prep_stream = nullptr;
     std::vector<hipEvent_t> sync_events;  // untimed events ordering the two streams
     bool overlap_prep = true;
-    bool sor_xcd_affine = true;      // all sweeps of a band on one XCD (block index -> task mapping, speed only)
+    int sor_xcd_affine = 1;          // 0: off; 1: when there are at most 8 bands; 2: always (see sor.hip)      // all sweeps of a band on one XCD (block index -> task mapping, speed only)
     // sequence mode (papof_seq_*): the pyramid of the last pushed frame stays in the arena and becomes "frame 1" of
     // the next pair.  Valid only while the arena block, the frame shape and the pyramid plan stay the same.
     struct Seq {

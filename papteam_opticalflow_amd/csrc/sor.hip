@@ -358,10 +358,19 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     // block indices only.
     int k, b;
     if (A.xcd_affine) {
-        const int x = blockIdx.x & 7, y = blockIdx.x >> 3, nb8 = (A.nb + 7) >> 3;
-        k = y / nb8;
-        b = (y - k * nb8) * 8 + x;
-        if (b >= A.nb) return;
+        // rows of S blocks per sweep, S a multiple of 8: the first 8 * (nb / 8) bands sit at their own index (band b on
+        // XCD b % 8 in every sweep); the nb % 8 remaining bands occupy consecutive places of one more group of 8 whose
+        // start moves with the sweep, so that they load every XCD equally instead of always the same ones
+        const int nf = A.nb >> 3, rem = A.nb & 7, S = 8 * nf + (rem ? 8 : 0);
+        k = blockIdx.x / S;
+        const int r = blockIdx.x - k * S;
+        if (r < 8 * nf) {
+            b = r;
+        } else {
+            const int j = r - 8 * nf - (nf ? k % (9 - rem) : 0);
+            if (j < 0 || j >= rem) return;
+            b = 8 * nf + j;
+        }
     } else {
         k = blockIdx.x / A.nb;
         b = blockIdx.x - k * A.nb;
@@ -1004,7 +1013,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         }
         // measured: with at most one band per XCD the affinity is worth 3-4 % (small pyramid levels); beyond that the
         // uneven band count per XCD costs more than the L2 hits give (1920x1080: 18 bands over 8 XCDs, -5 %)
-        A.xcd_affine = (h->sor_xcd_affine && sd.nb <= 8) ? 1 : 0;
+        A.xcd_affine = (h->sor_xcd_affine && (sd.nb <= 8 || h->sor_xcd_affine > 1)) ? 1 : 0;
         const dim3 grid(A.xcd_affine ? 8 * ((sd.nb + 7) / 8) * n_sor : sd.nb * n_sor), block(kLanes);
         // pipeline depth: every load is issued R steps ahead and a task looks 2R steps ahead of its producers, so R is
         // also what a hand-off costs.  Measured (profiles/r01_s2_sor_depth_sweep.txt): the big level wants the deeper
