@@ -79,7 +79,24 @@ def cpu_baseline(a, b, levels, sched, mode):
     return kind, dt
 
 
-def measure_tiles(args, gpu, dist, rank, world, d1, d2, h, w, c, sched, dvx, dvy, dwp):
+class stdout_to_stderr:
+    """RCCL prints a version banner to STDOUT when a communicator is created; this program's stdout carries exactly one
+    JSON line, so file descriptor 1 is pointed at stderr while communicators are being set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
+def measure_tiles(args, gpu, dist, rank, world, d1, d2, h, w, c, sched):
     """Secondary figure for N>1 (never `value`): ONE frame pair sharded as rows x cols tiles over all ranks, red-black
     SOR with ghost-zone halo exchange over RCCL (csrc/tiles.hip; BASELINE.json configs[4]) -- strong scaling of a
     single pair, next to the same red-black solve on one GPU.  A watchdog abandons a stuck collective: every rank
@@ -111,7 +128,10 @@ def measure_tiles(args, gpu, dist, rank, world, d1, d2, h, w, c, sched, dvx, dvy
             uid = bytes(idt.cpu().numpy().tobytes())
             state["phase"] = "comm_init"
             tr = capi.TileRank.create(gpu, uid, rank, world, rows, cols, args.tile_halo)
-            outs = (dvx, dvy, dwp) if rank == 0 else (None, None, None)
+            # own result buffers on rank 0: the headline run's (vx, vy) stay untouched for its parity statistic
+            dvx, dvy, dwp = ((gpu.dev_alloc(h * w * 8), gpu.dev_alloc(h * w * 8), gpu.dev_alloc(h * w * c * 8))
+                             if rank == 0 else (None, None, None))
+            outs = (dvx, dvy, dwp)
             state["phase"] = "warmup"
             tr.flow_device(d1, d2, h, w, c, args.levels, P, *outs)
             torch.cuda.synchronize()
@@ -143,6 +163,8 @@ def measure_tiles(args, gpu, dist, rank, world, d1, d2, h, w, c, sched, dvx, dvy
                 gpu.dev_download(sx, dvx)
                 gpu.dev_download(sy, dvy)
                 result["bit_identical_to_one_gpu_redblack"] = bool(np.array_equal(tx, sx) and np.array_equal(ty, sy))
+                for p_ in (dvx, dvy, dwp):
+                    gpu.dev_free(p_)
             dist.barrier()
             tr.close()
         except Exception as e:  # noqa: BLE001 -- reported, never silently replaced by another path
@@ -180,6 +202,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1")
     ap.add_argument("--no-tiles", action="store_true",
                     help="N>1: skip the secondary measurement of ONE pair sharded as 2-D tiles over all ranks")
+    ap.add_argument("--force-tiles", action="store_true",
+                    help="run the tiled measurement even with one rank (a tile group of one: no sends; exercises the RCCL "
+                         "bootstrap and the reporting code on a one-GPU box)")
     ap.add_argument("--tile-halo", type=int, default=10, help="ghost-zone depth of the tiled solve, in half-sweeps")
     ap.add_argument("--tiles-timeout", type=float, default=120.0,
                     help="seconds after which a stuck tiled measurement is abandoned (the JSON line is still printed)")
@@ -194,14 +219,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     use_cuda = not simulate
+    # PyTorch (its process group is only used for barriers / the max over ranks / the tile group's id) must touch the GPU
+    # BEFORE libpapof does: then both share PyTorch's HIP runtime; the other order leaves PyTorch without a device
     if world > 1:
         import torch
         import torch.distributed as dist
         if use_cuda:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", local_rank))
+            with stdout_to_stderr():
+                dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", local_rank))
+                dist.barrier()  # creates the communicator (and prints RCCL's banner) now, not inside the timed region
         else:
             dist.init_process_group(backend="gloo")
+    elif args.force_tiles and use_cuda:  # a process group of one
+        import socket
+        import torch
+        import torch.distributed as dist
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        torch.cuda.set_device(local_rank)
+        with stdout_to_stderr():
+            dist.init_process_group(backend=args.backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                    device_id=torch.device("cuda", local_rank))
+            dist.barrier()
 
     sched, mode = SCHEDULES[args.schedule], MODES[args.mode]
     if simulate:
@@ -270,8 +312,9 @@ def main():
         elapsed = float(tt.item())
 
     tiles = None
-    if world > 1 and use_cuda and not args.no_tiles:
-        tiles = measure_tiles(args, gpu, dist, rank, world, d1, d2, h, w, c, sched, dvx, dvy, dwp)
+    if use_cuda and not args.no_tiles and (world > 1 or args.force_tiles):
+        with stdout_to_stderr():
+            tiles = measure_tiles(args, gpu, dist, rank, world, d1, d2, h, w, c, sched)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -113,3 +113,25 @@ def test_rccl_transport_loads_and_runs_a_group_of_one(gpu):
         gpu.dev_free(p)
     want = gpu.coarse2fine_flow(a, b, 3, P)
     assert np.array_equal(vx, want[0]) and np.array_equal(wi, want[2])
+
+
+def test_bench_tiles_reporting_path_single_rank():
+    """bench.py's secondary tiled measurement (what `--gpus N` adds to the JSON line), forced on the one GPU of this box:
+    PyTorch process group of one, RCCL id + communicator, tile group of one, live bit-identity check, and still
+    exactly ONE line on stdout (RCCL prints its banner to stdout when a communicator is created)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--res", "240", "--steps", "2", "--warmup", "1",
+                          "--force-tiles", "--no-cpu-baseline", "--no-concurrent"], capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    t = r["tiles"]
+    assert "error" not in t, t
+    assert t["grid"] == "1x1" and t["bit_identical_to_one_gpu_redblack"] is True and t["value"] > 0
+    assert r["scaling"] == "weak" and t["scaling"] == "strong" and r["value"] > 0
