@@ -166,8 +166,7 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
     }
     for (int count = 0; count < n_outer; count++) {
         clk.phase(PAPOF_T_PHASE1_GENERATE);
-        PAPOF_TRY(filter_h(h, warp, B.tmp, H, W, fc, g));
-        PAPOF_TRY(smooth_v_blend(h, B.tmp, im1s, B.blend, B.imdt, H, W, fc));
+        PAPOF_TRY(smooth_hv_blend(h, warp, im1s, B.blend, B.imdt, H, W, fc));  // both passes + blend + imdt, fused
         // inner fixed-point iterations (src/OpticalFlow.cpp:290-506): after the first one, phi is taken at u + du and
         // psi at imdt + imdx*du + imdy*dv with the increment of the previous solve; the solve itself restarts at 0
         for (int hh = 0; hh < n_inner; hh++) {

@@ -205,6 +205,46 @@ __global__ void k_smooth_v_blend(const double* __restrict__ tmp, const double* _
     imdt[o] = s2 - s1;
 }
 
+// Both passes of the 5-tap smoothing of the warped frame + blend + imdt in ONE kernel (one-GPU path): a block owns
+// kFuseRows rows x 64 columns of one plane, filters kFuseRows + 4 rows horizontally into LDS (same taps, same order as
+// k_filter_h), then runs the vertical pass out of LDS (same order as k_smooth_v_blend).  The horizontally filtered
+// plane never goes to HBM: 4 instead of 6 plane transfers per channel, same bits.
+constexpr int kFuseRows = 16;
+__global__ __launch_bounds__(256) void k_smooth_hv_blend(const double* __restrict__ warp,
+                                                         const double* __restrict__ im1s,
+                                                         double* __restrict__ blend, double* __restrict__ imdt, int H,
+                                                         int W, Taps g) {
+    __shared__ double hs[kFuseRows + 4][BX];
+    const int j = blockIdx.x * BX + threadIdx.x, i0 = blockIdx.y * kFuseRows;
+    const size_t np = (size_t)H * W;
+    const double* src = warp + blockIdx.z * np;
+    if (j < W) {
+        for (int r = threadIdx.y; r < kFuseRows + 4; r += BY) {
+            const double* row = src + (size_t)clampi(i0 + r - 2, H) * W;
+            double acc = 0.0;
+#pragma unroll
+            for (int l = -2; l <= 2; l++) acc += row[clampi(j + l, W)] * g.t[l + 2];
+            hs[r][threadIdx.x] = acc;
+        }
+    }
+    __syncthreads();
+    if (j >= W) return;
+    for (int r = threadIdx.y; r < kFuseRows; r += BY) {
+        const int i = i0 + r;
+        if (i >= H) break;
+        const size_t o = blockIdx.z * np + (size_t)i * W + j;
+        double s2 = 0.0;
+#pragma unroll
+        for (int l = -2; l <= 2; l++) s2 += hs[r + l + 2][threadIdx.x] * g.t[l + 2];
+        const double s1 = im1s[o];
+        double t = s1;
+        t *= 0.4;
+        t += s2 * 0.6;
+        blend[o] = t;
+        imdt[o] = s2 - s1;
+    }
+}
+
 // index (in doubles) of cell (i, j) in an SOR operand plane.  Skew mode: paired planes, (phi,xy) (a1,a2) (b1,b2)
 // (du,dv) interleaved, cell (i, j) at (i + j + qt) * hp + (i + rt) -- see common.h.
 struct SkewIdx {
@@ -835,6 +875,14 @@ static SkewIdx skew_idx(const SorPlanes& sp) {
 static Increment increment_of(const SorPlanes* prev) {
     if (!prev) return Increment{nullptr, nullptr, 0, SkewIdx{0, 0, 0, 0, 0, 0, 0}};
     return Increment{prev->du, prev->dv, prev->skew ? 1 : 0, prev->skew ? skew_idx(*prev) : SkewIdx{0, 0, 0, 0, 0, 0, 0}};
+}
+
+int smooth_hv_blend(papof_handle* h, const double* warp, const double* im1s, double* blend, double* imdt, int H,
+                    int W, int planes) {
+    hipLaunchKernelGGL(k_smooth_hv_blend, dim3((W + BX - 1) / BX, (H + kFuseRows - 1) / kFuseRows, planes),
+                       dim3(BX, BY), 0, h->stream, warp, im1s, blend, imdt, H, W, smooth5_taps());
+    LAUNCH_CHECK();
+    return PAPOF_OK;
 }
 
 int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlanes* prev, double* phi, int H, int W,
