@@ -388,6 +388,10 @@ struct SystemCell {
     double phi, xy, a1, a2, b1, b2, x2, y2;
 };
 
+// EDGE = false: the cell is at least 2 pixels away from every image border, so no index needs clamping and every
+// neighbour exists -- the same operations in the same order with constant address offsets (the kernel is bound by
+// instruction issue, a third of it index arithmetic for the clamps).
+template <bool EDGE = true>
 __device__ __forceinline__ SystemCell assemble_cell(const double* __restrict__ blend, const double* __restrict__ imdt,
                                                     const double* __restrict__ phi, const double* __restrict__ u,
                                                     const double* __restrict__ v, int i, int j, int H, int W,
@@ -400,10 +404,18 @@ __device__ __forceinline__ SystemCell assemble_cell(const double* __restrict__ b
     for (int k = 0; k < planes; k++) {
         const double* im = blend + k * np;
         double gx = 0.0, gy = 0.0;
+        if (EDGE) {
 #pragma unroll
-        for (int l = -2; l <= 2; l++) gx += im[(size_t)i * W + clampi(j + l, W)] * d.t[l + 2];
+            for (int l = -2; l <= 2; l++) gx += im[(size_t)i * W + clampi(j + l, W)] * d.t[l + 2];
 #pragma unroll
-        for (int l = -2; l <= 2; l++) gy += im[(size_t)clampi(i + l, H) * W + j] * d.t[l + 2];
+            for (int l = -2; l <= 2; l++) gy += im[(size_t)clampi(i + l, H) * W + j] * d.t[l + 2];
+        } else {
+            const double* p = im + o;
+#pragma unroll
+            for (int l = -2; l <= 2; l++) gx += p[l] * d.t[l + 2];
+#pragma unroll
+            for (int l = -2; l <= 2; l++) gy += p[(ptrdiff_t)l * W] * d.t[l + 2];
+        }
         const double gt = imdt[k * np + o];
         double t = gt;  // imdt + imdx*du + imdy*dv (src/OpticalFlow.cpp:384); du = dv = 0 in the first inner iteration
         if (I.du != nullptr) t = gt + gx * du + gy * dv;
@@ -432,9 +444,33 @@ __device__ __forceinline__ SystemCell assemble_cell(const double* __restrict__ b
         sty = sty / planes;
     }
     SystemCell c;
-    c.b1 = -stx - alpha * laplacian_at(u, phi, i, j, H, W);
-    c.b2 = -sty - alpha * laplacian_at(v, phi, i, j, H, W);
-    sor_diagonals(phi, i, j, H, W, sx2, sy2, alpha, omega, c.a1, c.a2);
+    if (EDGE) {
+        c.b1 = -stx - alpha * laplacian_at(u, phi, i, j, H, W);
+        c.b2 = -sty - alpha * laplacian_at(v, phi, i, j, H, W);
+        sor_diagonals(phi, i, j, H, W, sx2, sy2, alpha, omega, c.a1, c.a2);
+    } else {  // laplacian_at / sor_diagonals with every neighbour present
+        const double pc = phi[o], pl = phi[o - 1], pu = phi[o - W];
+        const double uc = u[o], vc = v[o];
+        double lu = 0.0, lv = 0.0;
+        lu -= (u[o + 1] - uc) * pc;
+        lu += (uc - u[o - 1]) * pl;
+        lu -= (u[o + W] - uc) * pc;
+        lu += (uc - u[o - W]) * pu;
+        lv -= (v[o + 1] - vc) * pc;
+        lv += (vc - v[o - 1]) * pl;
+        lv -= (v[o + W] - vc) * pc;
+        lv += (vc - v[o - W]) * pu;
+        c.b1 = -stx - alpha * lu;
+        c.b2 = -sty - alpha * lv;
+        double coeff = 0.0;
+        coeff += pl;
+        coeff += pc;
+        coeff += pu;
+        coeff += pc;
+        coeff *= alpha;
+        c.a1 = omega / (sx2 + alpha * 0.05 + coeff);
+        c.a2 = omega / (sy2 + alpha * 0.05 + coeff);
+    }
     c.phi = phi[o];
     c.xy = sxy;
     c.x2 = sx2;
@@ -481,11 +517,15 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
                                                        double* __restrict__ o_y2, Taps d, Increment I) {
     __shared__ double stage[6][kBandRows][kTileJ + 1];
     const int b = blockIdx.y, j0 = blockIdx.x * kTileJ, tid = threadIdx.x;
+    // block-uniform: no cell of this tile is closer than 2 pixels to an image border
+    const bool interior = b * kBandRows >= 2 && b * kBandRows + kBandRows + 2 <= H && j0 >= 2 && j0 + kTileJ + 2 <= W;
     for (int c = tid; c < kBandRows * kTileJ; c += 256) {
         const int r = c / kTileJ, jj = c - r * kTileJ;
         const int i = b * kBandRows + r, j = j0 + jj;
         if (i < H && j < W) {
-            const SystemCell s = assemble_cell(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I);
+            const SystemCell s =
+                interior ? assemble_cell<false>(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I)
+                         : assemble_cell<true>(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I);
             stage[0][r][jj] = s.phi;
             stage[1][r][jj] = s.xy;
             stage[2][r][jj] = s.a1;
