@@ -415,6 +415,20 @@ def main():
                 for i in range(4):
                     gpu.seq_push(a8 if i % 2 == 0 else b8, args.levels, P)
                 out["sequence_u8_ms_per_frame"] = round((time.perf_counter() - th) / 4 * 1e3, 3)
+                from papteam_opticalflow_amd import flow_collection
+                kw = dict(n_outer=sched[0], n_outer_per_level=sched[1], n_sor=sched[2], n_sor_per_level=sched[3],
+                          sor_mode=mode, omega=1.8 if mode != 2 else 1.0)
+                video = [a8, b8] * 12 + [a8]  # 24 pairs
+                seen = []
+                flow_collection(video[:5], args.levels, in_flight=4, device=local_rank, on_pair=lambda i, *r: None, **kw)
+                th = time.perf_counter()
+                flow_collection(video, args.levels, in_flight=4, device=local_rank,
+                                on_pair=lambda i, t_, vx_, vy_, w_: seen.append(i), **kw)
+                dt = time.perf_counter() - th
+                assert sorted(seen) == list(range(24))
+                out["collection_u8_4_in_flight"] = {"pairs": 24, "ms_per_pair": round(dt / 24 * 1e3, 3),
+                                                    "value": round(24 * h * w / 1e6 / dt, 2), "unit": "Mpix/s",
+                                                    "note": "host uint8 frames in, float64 results out into reused arrays (PCIe-inclusive)"}
             except Exception as e:  # noqa: BLE001 -- secondary figures only
                 out["callers_side_error"] = "%s: %s" % (type(e).__name__, e)
         if world == 1 and not args.no_cpu_baseline and not simulate:

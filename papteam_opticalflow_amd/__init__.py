@@ -62,17 +62,18 @@ class FlowSequence:
     walks a 102-frame collection as 101 overlapping pairs, Code/Serial/TestSuite.py:69-81); results are bit-identical
     to calling coarse2fine_flow on each pair.  Frames may be float64 in [0,1] or uint8."""
 
-    def __init__(self, pyramidLevels, device=None, **solver):
+    def __init__(self, pyramidLevels, device=None, handle=None, **solver):
         import os
         self.levels = int(pyramidLevels)
         if self.levels < 1:
             raise ValueError("pyramidLevels must be >= 1")
         self.params = default_params(**solver) if solver else None
-        self.gpu = Papof(int(os.environ.get("PAPOF_DEVICE", "0")) if device is None else device)
+        self.gpu = handle if handle is not None else Papof(
+            int(os.environ.get("PAPOF_DEVICE", "0")) if device is None else device)
         self.gpu.seq_reset()
 
-    def push(self, frame):
-        r = self.gpu.seq_push(frame, self.levels, self.params)
+    def push(self, frame, out=None):
+        r = self.gpu.seq_push(frame, self.levels, self.params, out)
         if r is None:
             return None
         vx, vy, warp, t = r
@@ -113,3 +114,63 @@ def load_flow16(path):
         raise ValueError("not a 2-channel flow file")
     q = np.frombuffer(raw, dtype=np.uint16, offset=_FLOW16_HEADER).reshape(h, w, 2)
     return _handle().flow_dequantize16(q)
+
+
+_collection_handles = {}  # device -> handles kept between flow_collection calls (arena, staging and pinned buffers
+                          # of a handle cost tens of milliseconds to allocate)
+
+
+def flow_collection(frames, pyramidLevels, in_flight=4, device=None, on_pair=None, **solver):
+    """Flow of every consecutive pair of a frame list -- what the reference's TestSuite does with a collection
+    (Code/Serial/TestSuite.py:69-81: frame n -> n+1 for 101 pairs) -- with `in_flight` sequences running concurrently
+    on one GPU: the list is cut into contiguous segments (overlapping by one frame), each pushed through its own
+    FlowSequence (own handle, arena and streams) by its own host thread.  One pair alone leaves most of the chip idle
+    while the coarse pyramid levels are solved; several in flight fill it (bench.py `concurrent_pairs`).
+
+    on_pair(i, timing, vx, vy, warpI2), if given, is called for every pair (from the worker threads, in no particular
+    order) with arrays that are REUSED for the worker's next pair -- copy what you keep; nothing is returned.  This is
+    the fast form: 83 MB of fresh result memory per 1080p pair costs more in page faults than the GPU takes to fill
+    it.  Without on_pair the list of (timing, vx, vy, warpI2) in pair order is returned (fresh arrays).
+    Every result is bit-identical to coarse2fine_flow(frames[i], frames[i + 1], pyramidLevels)."""
+    import threading
+    import numpy as np
+    capi.load()  # once, in this thread
+    n_pairs = len(frames) - 1
+    if n_pairs < 1:
+        return None if on_pair else []
+    k = max(1, min(int(in_flight), n_pairs))
+    bounds = [n_pairs * s // k for s in range(k + 1)]  # segment s computes pairs bounds[s] .. bounds[s+1]-1
+    results, errors = [None] * n_pairs, []
+    import os
+    dev = int(os.environ.get("PAPOF_DEVICE", "0")) if device is None else int(device)
+    pool = _collection_handles.setdefault(dev, [])
+    while len(pool) < k:
+        pool.append(Papof(dev))
+
+    def run(s):
+        try:
+            seq = FlowSequence(pyramidLevels, handle=pool[s], **solver)
+            try:
+                out = None
+                for i in range(bounds[s], bounds[s + 1] + 1):
+                    if on_pair is not None and out is None and i > bounds[s]:
+                        h, w, c = np.shape(frames[i])
+                        out = (np.zeros((h, w)), np.zeros((h, w)), np.zeros((h, w, c)))
+                    r = seq.push(frames[i], out)
+                    if i > bounds[s]:
+                        if on_pair is not None:
+                            on_pair(i - 1, *r)
+                        else:
+                            results[i - 1] = r
+            finally:
+                seq.reset()  # the handle stays in the pool
+        except Exception as e:  # noqa: BLE001 -- re-raised in the caller's thread
+            errors.append(e)
+    threads = [threading.Thread(target=run, args=(s,)) for s in range(k)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return None if on_pair else results

@@ -31,6 +31,59 @@ void set_last_error(const char* what, hipError_t e, const char* file, int line) 
 const char* last_error() { return g_last_error.c_str(); }
 void set_last_error_text(const std::string& text) { g_last_error = text; }
 
+CopyPool::CopyPool(int workers) {
+    for (int i = 0; i < workers; i++) threads_.emplace_back([this] { loop(); });
+}
+
+CopyPool::~CopyPool() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+    }
+    wake_.notify_all();
+    for (auto& t : threads_) t.join();
+}
+
+void CopyPool::loop() {
+    for (;;) {
+        Job j;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            wake_.wait(lk, [this] { return stop_ || !jobs_.empty(); });
+            if (jobs_.empty()) return;  // stop
+            j = jobs_.back();
+            jobs_.pop_back();
+        }
+        std::memcpy(j.dst, j.src, j.n);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+}
+
+void CopyPool::copy(char* dst, const char* src, size_t n) {
+    const int parts = (int)threads_.size() + 1;
+    const size_t part = (n / parts + 4095) & ~size_t(4095);
+    int queued = 0;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (int t = 1; t < parts; t++) {
+            const size_t off = (size_t)t * part;
+            if (off >= n) break;
+            jobs_.push_back(Job{dst + off, src + off, std::min(part, n - off)});
+            queued++;
+        }
+        pending_ += queued;
+    }
+    if (queued) wake_.notify_all();
+    std::memcpy(dst, src, std::min(part, n));
+    if (queued) {
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+    }
+}
+
 static double wall() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -534,6 +587,7 @@ void papof_destroy(papof_handle* h) {
     if (h->sync_words) hipFree(h->sync_words);
     if (h->stage_dev) hipFree(h->stage_dev);
     if (h->pin) hipHostFree(h->pin);
+    delete h->pool;
     hipStreamDestroy(h->stream);
     delete h;
 }
@@ -641,22 +695,15 @@ int papof_seq_push_device(papof_handle* h, const void* d_frame, int is_u8, int h
 
 namespace {
 
-// Pageable user memory <-> pinned bounce buffer, split over a few host threads (one memcpy thread moves ~10 GB/s;
-// PCIe Gen5 wants ~50).
-void parallel_copy(char* dst, const char* src, size_t n, int threads) {
-    if (threads <= 1 || n < (size_t(4) << 20)) {
+// Pageable user memory <-> pinned bounce buffer through the handle's persistent copy pool (one memcpy thread moves
+// ~10 GB/s; PCIe Gen5 wants ~50).
+void parallel_copy(papof_handle* h, char* dst, const char* src, size_t n) {
+    if (h->host_threads <= 1 || n < (size_t(1) << 20)) {
         std::memcpy(dst, src, n);
         return;
     }
-    std::vector<std::thread> pool;
-    const size_t part = (n / threads + 4095) & ~size_t(4095);
-    for (int t = 1; t < threads; t++) {
-        const size_t off = (size_t)t * part;
-        if (off >= n) break;
-        pool.emplace_back([=] { std::memcpy(dst + off, src + off, std::min(part, n - off)); });
-    }
-    std::memcpy(dst, src, std::min(part, n));
-    for (auto& th : pool) th.join();
+    if (!h->pool) h->pool = new CopyPool(h->host_threads - 1);
+    h->pool->copy(dst, src, n);
 }
 
 int ensure_host_stage(papof_handle* h, size_t dev_bytes, size_t pin_bytes) {
@@ -693,7 +740,7 @@ constexpr size_t kChunk = size_t(8) << 20;  // bounce granularity: the DMA of on
 int upload_chunked(papof_handle* h, char* dev, const char* user, char* pin, size_t n) {
     for (size_t off = 0; off < n; off += kChunk) {
         const size_t m = std::min(kChunk, n - off);
-        parallel_copy(pin + off, user + off, m, h->host_threads);
+        parallel_copy(h, pin + off, user + off, m);
         PAPOF_HIP(hipMemcpyAsync(dev + off, pin + off, m, hipMemcpyHostToDevice, h->stream));
     }
     return PAPOF_OK;
@@ -724,8 +771,24 @@ int flow_host(papof_handle* h, const void* im1, const void* im2, bool u8, SeqOp 
     std::memset(tm, 0, sizeof tm);
     if (op != kSeqNext) PAPOF_TRY(upload_chunked(h, (char*)d1, (const char*)im1, h->pin, nb_in));
     if (op != kSeqPrime) PAPOF_TRY(upload_chunked(h, (char*)d2, (const char*)im2, h->pin + nb_img, nb_in));
-    PAPOF_TRY(device_call(h, FrameIn{d1, u8}, FrameIn{d2, u8}, op, height, width, c, pyramid_levels, params, dx, dy,
-                          dw, tm));
+    // The caller's result arrays are usually fresh allocations (pyflow.pyx: np.zeros per call): their first-touch page
+    // faults (~20k pages at 1080p, ~4 ms) are taken by a helper thread WHILE the GPU computes, not while copying back.
+    std::thread prefault;
+    if (op != kSeqPrime && np * sizeof(double) >= (size_t(1) << 20))
+        prefault = std::thread([=] {
+            const auto touch = [](double* p, size_t bytes) {
+                volatile char* q = reinterpret_cast<volatile char*>(p);
+                for (size_t o = 0; o < bytes; o += 4096) q[o] = 0;
+                if (bytes) q[bytes - 1] = 0;
+            };
+            touch(warpI2, nb_img);
+            touch(vx, nb_flow);
+            touch(vy, nb_flow);
+        });
+    const int rc_dev = device_call(h, FrameIn{d1, u8}, FrameIn{d2, u8}, op, height, width, c, pyramid_levels, params, dx,
+                                   dy, dw, tm);
+    if (prefault.joinable()) prefault.join();
+    PAPOF_TRY(rc_dev);
     if (op == kSeqPrime) {
         if (timing_sec) std::memcpy(timing_sec, tm, sizeof tm);
         return PAPOF_OK;
@@ -745,7 +808,7 @@ int flow_host(papof_handle* h, const void* im1, const void* im2, bool u8, SeqOp 
             char* dst[3] = {(char*)warpI2, (char*)vx, (char*)vy};
             for (int k = 0; k < 3; k++) {
                 const size_t lo = std::max(off, bounds[k]), hi = std::min(off + m, bounds[k + 1]);
-                if (lo < hi) parallel_copy(dst[k] + (lo - bounds[k]), h->pin + lo, hi - lo, h->host_threads);
+                if (lo < hi) parallel_copy(h, dst[k] + (lo - bounds[k]), h->pin + lo, hi - lo);
             }
         };
         int rc = PAPOF_OK;

@@ -14,9 +14,13 @@
 
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/papof.h"
@@ -141,6 +145,33 @@ struct SorPlanes {
 
 }  // namespace papof
 
+namespace papof {
+// A few persistent host threads per handle for the pageable <-> pinned copies of the host entry points (spawning
+// threads per 8-MiB chunk cost more than the copies; first-touch page faults of the caller's fresh result arrays are
+// spread over the workers).
+class CopyPool {
+public:
+    explicit CopyPool(int workers);
+    ~CopyPool();
+    void copy(char* dst, const char* src, size_t n);  // returns when all bytes are in place
+    int workers() const { return (int)threads_.size(); }
+
+private:
+    struct Job {
+        char* dst;
+        const char* src;
+        size_t n;
+    };
+    void loop();
+    std::vector<std::thread> threads_;
+    std::vector<Job> jobs_;
+    std::mutex mu_;
+    std::condition_variable wake_, done_;
+    int pending_ = 0;
+    bool stop_ = false;
+};
+}  // namespace papof
+
 struct papof_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -155,7 +186,8 @@ struct papof_handle {
     size_t stage_dev_bytes = 0;
     char* pin = nullptr;
     size_t pin_bytes = 0;
-    int host_threads = 4;            // threads used to move pageable user buffers to / from the pinned buffers
+    int host_threads = 6;            // threads used to move pageable user buffers to / from the pinned buffers
+    papof::CopyPool* pool = nullptr; // created by the first host-buffer call
     bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
     int sor_depth = 0;               // software-pipeline depth R (steps) of the exact-order SOR kernel; 0 = by level size
     unsigned long long* sor_dbg = nullptr;  // device buffer for per-task wait statistics (PAPOF_SOR_DBG)

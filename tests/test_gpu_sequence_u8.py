@@ -96,3 +96,26 @@ def test_package_level_sequence_and_u8_api():
     assert list(t) == list(t2) == list(t3) and all(isinstance(x, str) for x in t.values())
     assert np.array_equal(vx, vx2) and np.array_equal(vx, vx3) and np.array_equal(w, w3) and np.array_equal(vy, vy2)
     seq.close()
+
+
+def test_collection_in_flight_equals_pairwise(gpu):
+    """flow_collection: several sequences in flight on one GPU (threads, one handle each) give, pair by pair, the bits
+    of the pairwise call."""
+    from papteam_opticalflow_amd import flow_collection
+    frames = _frames("240", 3)
+    frames = [frames[0], frames[1], frames[2], frames[1], frames[0], frames[2]]  # 5 pairs out of the 3 fixtures
+    got = flow_collection(frames, 3, in_flight=3)
+    assert len(got) == 5 and all(g is not None for g in got)
+    for i, (t, vx, vy, w) in enumerate(got):
+        want = gpu.coarse2fine_flow(_f64(frames[i]), _f64(frames[i + 1]), 3)
+        assert np.array_equal(vx, want[0]) and np.array_equal(vy, want[1]) and np.array_equal(w, want[2]), i
+        assert isinstance(t["Total C++ Execution"], str)
+    kept = {}
+    assert flow_collection(frames, 3, in_flight=2, on_pair=lambda i, t_, vx_, vy_, w_: kept.__setitem__(
+        i, (vx_.copy(), vy_.copy(), w_.copy()))) is None  # callback form: arrays are reused, so copy what is kept
+    assert sorted(kept) == [0, 1, 2, 3, 4]
+    for i in range(5):
+        assert all(np.array_equal(x, y) for x, y in zip(kept[i], got[i][1:]))
+    assert flow_collection(frames[:1], 3) == []
+    one = flow_collection(frames[:2], 3, in_flight=8)
+    assert len(one) == 1 and np.array_equal(one[0][1], got[0][1])
