@@ -265,12 +265,16 @@ def test_pyflow_dropin_entry_point(oracle):
         pyflow.coarse2fine_flow(a.astype(np.float32), b.astype(np.float32), 2)
 
 
-@pytest.mark.parametrize("group", ["2", "4"])
-def test_grouped_sor_kernel_matches_oracle(oracle, group, monkeypatch):
-    """The opt-in grouped solver (PAPOF_SOR_GROUP: M sweeps of a band per workgroup, LDS hand-off; sor.hip
-    k_sor_group) must give the reference's bits too."""
+@pytest.mark.parametrize("knob,value", [("PAPOF_SOR_GROUP", "2"), ("PAPOF_SOR_GROUP", "4"), ("PAPOF_SOR_DEPTH", "4"),
+                                        ("PAPOF_SOR_DEPTH", "8"), ("PAPOF_SOR_DEPTH", "12"), ("PAPOF_SOR_XCD", "0"),
+                                        ("PAPOF_SOR_XCD", "2"), ("PAPOF_OVERLAP", "0"), ("PAPOF_SOR_XLANE", "shfl")])
+def test_every_solver_variant_matches_oracle(oracle, knob, value, monkeypatch):
+    """Every tuning knob selects code that must give the reference's bits too: the opt-in grouped solver
+    (PAPOF_SOR_GROUP: M sweeps of a band per workgroup, LDS hand-off; sor.hip k_sor_group), the pipeline depths the
+    size heuristic does not pick, the XCD mappings, the single-stream orchestration, the ds_bpermute lane shifts."""
     from papteam_opticalflow_amd import Papof
-    monkeypatch.setenv("PAPOF_SOR_GROUP", group)
+    group = knob + "=" + value
+    monkeypatch.setenv(knob, value)
     g = Papof(0)  # the environment is read when the handle is created
     try:
         for h, w, n_sor in [(70, 50, 4), (130, 37, 3), (1, 5, 3), (129, 3, 2), (341, 607, 42), (540, 960, 30),
