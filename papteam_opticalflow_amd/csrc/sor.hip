@@ -445,7 +445,13 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     // loop header joins two states with the same pipeline contents (after an iteration / after an iteration).
     const auto iteration = [&](int i, bool first) -> bool {
         if (!first && !wait_covered(A, pl, D, (i + 2) * R)) return false;
-        const Polls pn = poll(D);  // poll for iteration i + 1
+        // The poll for the next iteration's check is consumed at the start of the next iteration, where it waits (in
+        // order) for every load issued before it.  Issued in the middle of this iteration it is half an iteration fresher
+        // (a shorter hand-off) but then waits for the refills of the first half: at R = 10 those are 5 steps old and long
+        // there (level 0: 1.10 -> 1.08 ms), at R = 6 only 3 steps (0.47 -> 0.58 ms).  Hence by depth.
+        constexpr bool kMidPoll = R >= 10;
+        Polls pn{0u, 0u, 0u};
+        if (!kMidPoll) pn = poll(D);
         // Markers are consumed DM = R - 3 steps after they were issued -- i.e. in the NEXT iteration: consuming a marker
         // waits (in-order vmcnt) for every load issued before it, and with DM = 3 that exposed ~0.35 us of latency twice
         // per iteration (the refills issued in those 3 steps).  R - 3 steps later all of them have long arrived.
@@ -459,6 +465,7 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
         }
         Seg<R, CA, H, DPP>::run(A, T, L, om1, i * R, c, S);
         ma = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // marker A: after step H - 1
+        if (kMidPoll) pn = poll(D);
         Seg<R, H, CB, DPP>::run(A, T, L, om1, i * R, c, S);
         if (!first) {  // marker B of the previous iteration: steps < i R are complete
             asm volatile("" ::"v"(mb), "v"(S.duL), "v"(S.dvL) : "memory");
