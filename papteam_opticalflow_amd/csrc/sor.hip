@@ -1023,9 +1023,10 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.xcd_affine = (h->sor_xcd_affine && (sd.nb <= 8 || h->sor_xcd_affine > 1)) ? 1 : 0;
         const dim3 grid(A.xcd_affine ? 8 * ((sd.nb + 7) / 8) * n_sor : sd.nb * n_sor), block(kLanes);
         // pipeline depth: every load is issued R steps ahead and a task looks 2R steps ahead of its producers, so R is
-        // also what a hand-off costs.  Measured (profiles/r01_s2_sor_depth_sweep.txt): the big level wants the deeper
-        // pipeline (throughput), the smaller, hand-off-bound levels the shorter one (607x341: 0.53 -> 0.47 ms).
-        const int R = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 16 ? 10 : 6);
+        // also what a hand-off costs.  Measured (profiles/r01_s2_sor_depth_sweep.txt): the big levels want the deeper
+        // pipeline (throughput; with the mid-iteration poll 1440x810: 0.85 -> 0.81 ms, 1080x607: 0.68 -> 0.65 ms), the
+        // small, hand-off-bound levels the shorter one (607x341: 0.53 -> 0.47 ms).
+        const int R = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 9 ? 10 : 6);
         if (!h->use_dpp)
             hipLaunchKernelGGL((k_sor_exact<8, false>), grid, block, 0, h->stream, A);
         else if (R <= 4)
