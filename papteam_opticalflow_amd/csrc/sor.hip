@@ -658,8 +658,7 @@ struct GWaveCtx {  // wave-uniform
 template <int R, bool DPP, bool FROM_LDS, bool TO_LDS>
 __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, const GLane& L, const GWaveCtx& W,
                                            unsigned lane, double om1) {
-    constexpr int H = R / 2, DM = 3;
-    static_assert(H > DM, "marker distance must fit in half an iteration");
+    constexpr int H = R / 2;
     const int ns = W.ns;
     ExactArgs X;  // the waiting helpers only look at these
     X.abort = A.abort;
@@ -717,35 +716,46 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
         }
     };
 
-    unsigned mb = 0u;
-    for (int i = 0; i < W.n_iter; ++i) {
+    // markers consumed R - 3 steps after issue, in the next iteration, and the first iteration peeled -- as in
+    // k_sor_exact (see there)
+    constexpr int DL = R - 3, CA = H + DL - R, CB = DL;
+    static_assert(CA >= 0 && CA < H && CB >= H && CB < R, "marker consumption points");
+    unsigned ma = 0u, mb = 0u;
+    const auto iteration = [&](int i, bool first) -> bool {
         const unsigned long long tc = dbg ? __builtin_amdgcn_s_memtime() : 0;
-        if (i > 0 && !wait_covered(X, pl, W.D, (i + 2) * R)) return give_up();
+        if (!first && !wait_covered(X, pl, W.D, (i + 2) * R)) return false;
         if (dbg) t_cov += __builtin_amdgcn_s_memtime() - tc;
         const Polls pn = poll(W.D);
         const int s0 = i * R;
-        if (!half_begin(s0)) return give_up();
-        GSeg<R, 0, DM, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
-        if (i > 0) {
+        if (!half_begin(s0)) return false;
+        GSeg<R, 0, CA, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
+        if (!first) {  // marker A of the previous iteration
+            asm volatile("" ::"v"(ma), "v"(S.duL), "v"(S.dvL) : "memory");
+            if (ma != 0u) return false;
+            if (lane == 0)
+                __hip_atomic_store(W.my_prog, (unsigned)min(ns, s0 - R + H), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        GSeg<R, CA, H, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
+        ma = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // marker A: after step H - 1
+        half_end(s0);
+        if (!half_begin(s0 + H)) return false;
+        GSeg<R, H, CB, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
+        if (!first) {  // marker B of the previous iteration
             asm volatile("" ::"v"(mb), "v"(S.duL), "v"(S.dvL) : "memory");
-            if (mb != 0u) return give_up();
+            if (mb != 0u) return false;
             if (lane == 0)
                 __hip_atomic_store(W.my_prog, (unsigned)min(ns, s0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        GSeg<R, DM, H, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
-        const unsigned ma = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        half_end(s0);
-        if (!half_begin(s0 + H)) return give_up();
-        GSeg<R, H, H + DM, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
-        asm volatile("" ::"v"(ma), "v"(S.duL), "v"(S.dvL) : "memory");
-        if (ma != 0u) return give_up();
-        if (lane == 0)
-            __hip_atomic_store(W.my_prog, (unsigned)min(ns, s0 + H), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        GSeg<R, H + DM, R, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
-        mb = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        GSeg<R, CB, R, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
+        mb = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // marker B: after step R - 1
         half_end(s0 + H);
         pl = pn;
-    }
+        return true;
+    };
+    if (!iteration(0, true)) return give_up();
+    for (int i = 1; i < W.n_iter; ++i)
+        if (!iteration(i, false)) return give_up();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(W.my_prog, (unsigned)ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (dbg && lane == 0) {
@@ -759,7 +769,7 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
 
 template <int R, int M, bool DPP>
 __global__ __launch_bounds__(64 * M) void k_sor_group(GroupArgs A) {
-    static_assert(R >= 8 && R % 2 == 0 && R <= kRing, "half-iterations of R/2 steps; the ring holds two of them");
+    static_assert(R >= 6 && R % 2 == 0 && R <= kRing, "half-iterations of R/2 steps; the ring holds two of them");
     __shared__ u32x4 ring[(M > 1 ? M - 1 : 1) * kRing * kLanes];
     __shared__ unsigned lds_done[M];   // [m]: steps of wave m whose cells are in its ring
     __shared__ unsigned lds_taken[M];  // [m]: steps of ring m the wave after has read
@@ -1005,12 +1015,15 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             const int groups = (n_sor + sd.group - 1) / sd.group;
             Ga.xcd_affine = (h->sor_xcd_affine && sd.nb <= 8) ? 1 : 0;
             const dim3 ggrid(Ga.xcd_affine ? 8 * ((sd.nb + 7) / 8) * groups : sd.nb * groups);
-            if (sd.group == 4 && h->sor_depth >= 12)
+            const int Rg = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 9 ? 10 : 8);
+            if (sd.group == 4 && Rg >= 12)
                 hipLaunchKernelGGL((k_sor_group<12, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
-            else if (sd.group == 4 && h->sor_depth >= 10)
+            else if (sd.group == 4 && Rg >= 10)
                 hipLaunchKernelGGL((k_sor_group<10, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
-            else if (sd.group == 4)
+            else if (sd.group == 4 && Rg >= 8)
                 hipLaunchKernelGGL((k_sor_group<8, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
+            else if (sd.group == 4)
+                hipLaunchKernelGGL((k_sor_group<6, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
             else if (sd.group == 2)
                 hipLaunchKernelGGL((k_sor_group<8, 2, true>), ggrid, dim3(kLanes * 2), 0, h->stream, Ga);
             else
@@ -1092,7 +1105,8 @@ int sor_reset_planes(papof_handle* h, const SorPlanes& sp) {
 int sor_group_size(const papof_handle* h, int H, int W, int n_sor) {
     if (!h || !h->use_dpp || n_sor < 2) return 1;
     int g = h->sor_group;
-    if (g == 0) g = 1;  // measured: grouping wins 5-20 % on isolated small solves, nothing end to end
+    if (g == 0) g = 1;  // measured: an isolated 240x135 solve gains 17 % (0.25 -> 0.21 ms), but end to
+                        // end nothing at any size (13.6 vs 13.7 ms for a 240x135 pair): stays opt-in
     if (g >= 4) return 4;  // LDS (160 KB) holds the rings of up to 4 waves... and 4 waves = one per SIMD
     return g >= 2 ? 2 : 1;
 }
