@@ -171,6 +171,13 @@ int papof_tiles_flow_device(papof_tiles* t, const double* d_im1, const double* d
 int papof_tiles_stats(const papof_tiles* t, long* exchanges, size_t* bytes); /* of the last call, this rank */
 void papof_tiles_destroy(papof_tiles* t);
 
+/* hipGraph replay of whole calls (also PAPOF_GRAPH=1 when the handle is created).  A call with given arguments runs
+ * eagerly the first time, is captured (both streams, every kernel, memset and copy) the second time and is one
+ * hipGraphLaunch from then on; only "Total C++ Execution" is timed in that mode.  For small frames, and for several
+ * calls in flight, the host-side launch path is the limit: 240x135 pairs on the reference schedule are ~700 launches
+ * each.  Results are the same bits. */
+int papof_set_graph_mode(papof_handle* h, int on);
+
 /* Device memory helpers for callers without a HIP binding (bench.py, ctypes users). */
 int papof_dev_alloc(papof_handle* h, size_t bytes, void** out);
 int papof_dev_free(papof_handle* h, void* p);

@@ -294,9 +294,87 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     const int fc = feature_channels(C);
     double tm[PAPOF_N_TIMERS];
     std::memset(tm, 0, sizeof tm);
-    PhaseClock clk{h, P.phase_timing != 0};
-    PhaseClock sorclk{h, P.phase_timing == 0};
-    PhaseClock total{h, true};
+
+    // ---- hipGraph mode: eager on the first call with these arguments, captured on the second, replayed afterwards
+    enum { kEager, kCapture, kReplay } gmode = kEager;
+    GraphEntry* ge = nullptr;
+    if (h->use_graph && op != kSeqPrime && P.phase_timing == 0) {
+        GraphKey key;
+        std::memset(&key, 0, sizeof key);
+        key.H = H;
+        key.W = W;
+        key.C = C;
+        key.levels = levels;
+        key.op = (int)op;
+        key.slot1 = slot1;
+        key.u8 = fb.u8 ? 1 : 0;
+        key.P = P;
+        key.fa = op == kSeqNext ? nullptr : fa.d;
+        key.fb = fb.d;
+        key.vx = d_vx;
+        key.vy = d_vy;
+        key.warp = d_warp;
+        key.arena_base = A.base;
+        for (GraphEntry& e : h->graphs)
+            if (std::memcmp(&e.key, &key, sizeof key) == 0) ge = &e;
+        if (!ge) {
+            if (h->graphs.size() >= 8) {  // a handful of shapes per handle is the use case; start over beyond that
+                for (GraphEntry& e : h->graphs)
+                    if (e.exec) hipGraphExecDestroy(e.exec);
+                h->graphs.clear();
+            }
+            h->graphs.push_back(GraphEntry{});
+            ge = &h->graphs.back();
+            ge->key = key;
+        }
+        gmode = ge->exec ? kReplay : (ge->seen >= 1 ? kCapture : kEager);
+        ge->seen++;
+    }
+    const auto keep_seq = [&](int slot) {
+        h->seq.valid = true;
+        h->seq.h = H;
+        h->seq.w = W;
+        h->seq.c = C;
+        h->seq.levels = levels;
+        h->seq.ratio = ratio;
+        h->seq.slot = slot;
+        h->seq.arena_base = A.base;
+    };
+    const auto launch_graph = [&]() -> int {  // replay + the only two timers a graph call has: total, and nothing else
+        hipEvent_t e0, e1;
+        PAPOF_HIP(hipEventCreate(&e0));
+        PAPOF_HIP(hipEventCreate(&e1));
+        hipEventRecord(e0, h->stream);
+        hipError_t ge_rc = hipGraphLaunch(ge->exec, h->stream);
+        hipEventRecord(e1, h->stream);
+        hipError_t sy = hipStreamSynchronize(h->stream);
+        float ms = 0;
+        if (ge_rc == hipSuccess && sy == hipSuccess) hipEventElapsedTime(&ms, e0, e1);
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        if (ge_rc != hipSuccess || sy != hipSuccess) {
+            set_last_error("hipGraphLaunch", ge_rc != hipSuccess ? ge_rc : sy, __FILE__, __LINE__);
+            return PAPOF_EDEVICE;
+        }
+        if (P.sor_mode == PAPOF_SOR_EXACT) PAPOF_TRY(sor_check(h));
+        tm[PAPOF_T_TOTAL] = ms * 1e-3;
+        if (timing) std::memcpy(timing, tm, sizeof tm);
+        if (op == kSeqNext) keep_seq(slot1 ^ 1);
+        return PAPOF_OK;
+    };
+    if (gmode == kReplay) return launch_graph();
+    const bool capturing = gmode == kCapture;
+    if (capturing) {
+        hipError_t ce = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+        if (ce != hipSuccess) {  // no graphs on this runtime: stay eager
+            h->use_graph = false;
+            gmode = kEager;
+        }
+    }
+    const bool in_capture = gmode == kCapture;
+    PhaseClock clk{h, P.phase_timing != 0 && !in_capture};
+    PhaseClock sorclk{h, P.phase_timing == 0 && !in_capture};
+    PhaseClock total{h, !in_capture};
 
     total.phase(PAPOF_T_TOTAL);
     clk.phase(PAPOF_T_CONSTRUCTION);
@@ -413,7 +491,14 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     {
         const int rc = prepare();
         if (rc != PAPOF_OK) {
-            if (overlap) hipStreamSynchronize(prep);
+            if (in_capture) {
+                hipGraph_t graph = nullptr;
+                hipStreamEndCapture(main_stream, &graph);
+                if (graph) hipGraphDestroy(graph);
+                h->use_graph = false;
+            } else if (overlap) {
+                hipStreamSynchronize(prep);
+            }
             return rc;
         }
     }
@@ -455,6 +540,20 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         return PAPOF_OK;
     };
     rc_main = solve_levels();
+    if (in_capture) {  // close the capture whatever happened; a failed capture falls back to eager calls for good
+        hipGraph_t graph = nullptr;
+        hipError_t ee = hipStreamEndCapture(main_stream, &graph);
+        if (rc_main == PAPOF_OK && ee == hipSuccess && graph &&
+            hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            hipGraphDestroy(graph);
+            return launch_graph();
+        }
+        if (graph) hipGraphDestroy(graph);
+        ge->exec = nullptr;
+        h->use_graph = false;
+        g_last_error = "hipGraph capture failed; graph mode switched off for this handle";
+        return rc_main != PAPOF_OK ? rc_main : PAPOF_EDEVICE;
+    }
     if (rc_main != PAPOF_OK) {  // never leave work of this call running on either stream
         hipStreamSynchronize(main_stream);
         if (overlap) hipStreamSynchronize(prep);
@@ -561,6 +660,7 @@ int papof_create(int device, papof_handle** out) {
         papof_destroy(h);
         return PAPOF_ENODEVICE;
     }
+    if (const char* cs = std::getenv("PAPOF_GRAPH")) h->use_graph = std::atoi(cs) != 0;
     if (const char* cs = std::getenv("PAPOF_OVERLAP")) h->overlap_prep = std::atoi(cs) != 0;
     if (const char* cs = std::getenv("PAPOF_HOST_THREADS")) h->host_threads = std::max(1, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_SOR_DEPTH")) h->sor_depth = std::max(4, std::atoi(cs));
@@ -582,6 +682,8 @@ void papof_destroy(papof_handle* h) {
     if (h->prep_stream) hipStreamSynchronize(h->prep_stream);
     for (hipEvent_t e : h->events) hipEventDestroy(e);
     for (hipEvent_t e : h->sync_events) hipEventDestroy(e);
+    for (papof::GraphEntry& e : h->graphs)
+        if (e.exec) hipGraphExecDestroy(e.exec);
     if (h->prep_stream) hipStreamDestroy(h->prep_stream);
     if (h->arena.base) hipFree(h->arena.base);
     if (h->sync_words) hipFree(h->sync_words);
@@ -673,6 +775,12 @@ int papof_flow_device_u8(papof_handle* h, const unsigned char* d_im1, const unsi
                          double* d_vy, double* d_warpI2, double timing_sec[PAPOF_N_TIMERS]) {
     return device_call(h, FrameIn{d_im1, true}, FrameIn{d_im2, true}, kPair, height, width, c, pyramid_levels, params,
                        d_vx, d_vy, d_warpI2, timing_sec);
+}
+
+int papof_set_graph_mode(papof_handle* h, int on) {
+    if (!h) return PAPOF_EINVAL;
+    h->use_graph = on != 0;
+    return PAPOF_OK;
 }
 
 int papof_seq_reset(papof_handle* h) {

@@ -172,6 +172,24 @@ private:
 };
 }  // namespace papof
 
+namespace papof {
+// One captured call (hipGraph): everything flow_device enqueues for a given problem -- both streams, ~200 nodes at
+// 1080p, ~700 on the reference schedule -- replayed with a single launch.  Valid for exactly these arguments (the arena
+// layout is a pure function of them; pointers are part of the key).
+struct GraphKey {
+    int H, W, C, levels, op, slot1, u8;
+    papof_params P;
+    const void *fa, *fb;
+    void *vx, *vy, *warp;
+    const void* arena_base;
+};
+struct GraphEntry {
+    GraphKey key;
+    int seen = 0;  // eager calls with this key so far (the first one sizes every lazily grown buffer)
+    hipGraphExec_t exec = nullptr;
+};
+}  // namespace papof
+
 struct papof_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -188,6 +206,11 @@ struct papof_handle {
     size_t pin_bytes = 0;
     int host_threads = 6;            // threads used to move pageable user buffers to / from the pinned buffers
     papof::CopyPool* pool = nullptr; // created by the first host-buffer call
+    // hipGraph replay of whole calls (PAPOF_GRAPH=1 / papof_set_graph_mode): for small frames a call is hundreds of
+    // launches of a few microseconds of work each, and with several calls in flight the host-side launch path is the
+    // limit; captured once (on the second call with the same arguments) a call becomes one hipGraphLaunch
+    bool use_graph = false;
+    std::vector<papof::GraphEntry> graphs;
     bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
     int sor_depth = 0;               // software-pipeline depth R (steps) of the exact-order SOR kernel; 0 = by level size
     unsigned long long* sor_dbg = nullptr;  // device buffer for per-task wait statistics (PAPOF_SOR_DBG)

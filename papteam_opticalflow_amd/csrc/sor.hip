@@ -1201,9 +1201,13 @@ int sor_probe_dpp(papof_handle* h) {
 int sor_check(papof_handle* h) {
     if (!h->sync_words) return PAPOF_OK;
     unsigned flag = 0;
-    PAPOF_HIP(hipMemcpy(&flag, h->sync_words, sizeof(unsigned), hipMemcpyDeviceToHost));
+    // on the handle's own stream: the legacy stream would synchronise with every other stream of the process, and is
+    // off limits while another thread captures a graph
+    PAPOF_HIP(hipMemcpyAsync(&flag, h->sync_words, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
     if (flag != 0) {
-        PAPOF_HIP(hipMemset(h->sync_words, 0, sizeof(unsigned)));
+        PAPOF_HIP(hipMemsetAsync(h->sync_words, 0, sizeof(unsigned), h->stream));
+        PAPOF_HIP(hipStreamSynchronize(h->stream));
         return PAPOF_ETIMEOUT;
     }
     return PAPOF_OK;

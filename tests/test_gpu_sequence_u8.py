@@ -119,3 +119,41 @@ def test_collection_in_flight_equals_pairwise(gpu):
     assert flow_collection(frames[:1], 3) == []
     one = flow_collection(frames[:2], 3, in_flight=8)
     assert len(one) == 1 and np.array_equal(one[0][1], got[0][1])
+
+
+def test_graph_mode_replays_the_same_bits(gpu, oracle):
+    """papof_set_graph_mode: the second call with the same arguments is captured into a hipGraph (both streams, every
+    kernel / memset / copy), later calls replay it with one launch.  Eager, capturing and replaying calls must all
+    return the oracle's bits; sequences (two graphs, one per pyramid-slot parity) and other shapes in between too."""
+    from papteam_opticalflow_amd import Papof, default_params
+    frames = _frames("240", 3)
+    f = [_f64(x) for x in frames]
+    want01 = oracle.coarse2fine_flow(f[0], f[1], 3)[:3]
+    g = Papof(0)
+    g.set_graph_mode(True)
+    try:
+        for call in range(4):  # eager, capture, replay, replay
+            got = g.coarse2fine_flow(f[0], f[1], 3)
+            for x, y in zip(got[:3], want01):
+                assert np.array_equal(x, y), call
+            assert got[3][9] > 0
+        P = default_params(n_outer=2, n_outer_per_level=0, n_sor=5, n_sor_per_level=0, sor_mode=1)
+        for call in range(3):  # other parameters and sweep order: their own graph
+            got = g.coarse2fine_flow_u8(frames[1], frames[2], 4, P)
+            want = gpu.coarse2fine_flow(f[1], f[2], 4, P)
+            assert all(np.array_equal(x, y) for x, y in zip(got[:3], want[:3])), call
+        pair = [gpu.coarse2fine_flow(f[i], f[i + 1], 3)[:3] for i in range(2)]
+        g.seq_reset()
+        feed = [frames[0], frames[1], frames[2]] * 4
+        expect = [None, pair[0], pair[1], gpu.coarse2fine_flow(f[2], f[0], 3)[:3]]
+        for i, fr in enumerate(feed):
+            out = g.seq_push(fr, 3)
+            if i == 0:
+                assert out is None
+                continue
+            w_ = expect[1 + (i - 1) % 3]
+            assert all(np.array_equal(x, y) for x, y in zip(out[:3], w_)), i
+        got = g.coarse2fine_flow(f[0], f[1], 3)  # the pair graph from the beginning is still valid
+        assert all(np.array_equal(x, y) for x, y in zip(got[:3], want01))
+    finally:
+        g.close()
