@@ -99,7 +99,8 @@ size_t arena_bytes_for(int H, int W, int C, int levels, int n_sor_max, double ra
         if (levels >= 1 && pyramid_plan(H, W, ratio, levels, L, plan) == PAPOF_OK)
             for (const Level& l : L) per_level += ((size_t)l.w * l.h * fc * sizeof(double) + 256) * 3;
     }
-    const SkewDims sd = skew_dims(H, W, n_sor_max, 2);
+    size_t sor_cells = 0, sor_cells_d = 0;
+    skew_capacity(H, W, n_sor_max, sor_cells, sor_cells_d);
     size_t planes = 0;
     planes += (size_t)2 * C * 5;           // two pyramids: sum of ratio^(2i) < 2.3 for ratio<=.75; 5 is safe to .98
     if (levels > 8) planes += (size_t)2 * C * levels;  // (ratio .98 decays slowly: bound by level count)
@@ -108,10 +109,16 @@ size_t arena_bytes_for(int H, int W, int C, int levels, int n_sor_max, double ra
     planes += 8;                           // u, v, resized u, v, phi + slack
     planes += (size_t)3 * C + C;           // bicubic derivative planes + interleaved output
     size_t bytes = planes * np * sizeof(double);
-    bytes += 3 * (sd.n + 2 * kLanes) * 16 + (sd.nd + sd.nh + 2 * kLanes) * 16 + 10 * np * sizeof(double);  // SOR operands
+    bytes += 3 * (sor_cells + 2 * kLanes) * 16 + (sor_cells_d + 2 * kLanes) * 16 + 10 * np * sizeof(double);  // SOR operands
     bytes += per_level + np * fc * sizeof(double);  // + the preparation stream's own filter temporary
     bytes += (size_t)64 * 4096;            // alignment slack
     return bytes;
+}
+
+static size_t sor_scratch_bytes(int H, int W, int n_sor) {  // the four paired operand planes of one solve
+    size_t cells = 0, cells_d = 0;
+    skew_capacity(H, W, n_sor, cells, cells_d);
+    return 4 * (cells + 128) * 16 + (cells_d + 128) * 16;
 }
 
 int ensure_arena(papof_handle* h, size_t bytes) {
@@ -664,6 +671,7 @@ int papof_create(int device, papof_handle** out) {
     if (const char* cs = std::getenv("PAPOF_OVERLAP")) h->overlap_prep = std::atoi(cs) != 0;
     if (const char* cs = std::getenv("PAPOF_HOST_THREADS")) h->host_threads = std::max(1, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_SOR_DEPTH")) h->sor_depth = std::max(4, std::atoi(cs));
+    if (const char* cs = std::getenv("PAPOF_SOR_FUSE")) h->sor_fuse = std::max(1, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_SOR_GROUP")) h->sor_group = std::max(1, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_SOR_XCD")) h->sor_xcd_affine = std::atoi(cs);
     int rc = sor_probe_dpp(h);
@@ -1250,7 +1258,7 @@ int papof_stage_sor(papof_handle* h, const double* phi, const double* imdxy, con
         n_sor < 1 || sor_mode < PAPOF_SOR_EXACT || sor_mode > PAPOF_SOR_JACOBI)
         return PAPOF_EINVAL;
     const size_t np = (size_t)height * width;
-    Scope S(h, img_bytes(height, width, 1, 16) + 4 * (skew_dims(height, width, n_sor).n + 128) * 16 + (skew_dims(height, width, n_sor, 2).nd + skew_dims(height, width, n_sor, 2).nh + 128) * 16 +
+    Scope S(h, img_bytes(height, width, 1, 16) + sor_scratch_bytes(height, width, n_sor) +
                    12 * (size_t)height * width * sizeof(double));
     PAPOF_TRY(S.rc);
     double* p = S.up_planar(phi, height, width, 1);
@@ -1280,7 +1288,7 @@ int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2
         return PAPOF_EINVAL;
     if (n_inner < 1) return PAPOF_EINVAL;
     Scope S(h, img_bytes(height, width, c, 12) + img_bytes(height, width, 1, 8) +
-                   4 * (skew_dims(height, width, n_sor).n + 128) * 16 + (skew_dims(height, width, n_sor, 2).nd + skew_dims(height, width, n_sor, 2).nh + 128) * 16 +
+                   sor_scratch_bytes(height, width, n_sor) +
                    12 * (size_t)height * width * sizeof(double));
     PAPOF_TRY(S.rc);
     double* f1 = S.up_planar(im1, height, width, c);
@@ -1384,7 +1392,7 @@ int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_m
         sor_mode > PAPOF_SOR_JACOBI)
         return PAPOF_EINVAL;
     const size_t np = (size_t)height * width;
-    Scope S(h, img_bytes(height, width, 1, 16) + 4 * (skew_dims(height, width, n_sor).n + 128) * 16 + (skew_dims(height, width, n_sor, 2).nd + skew_dims(height, width, n_sor, 2).nh + 128) * 16 +
+    Scope S(h, img_bytes(height, width, 1, 16) + sor_scratch_bytes(height, width, n_sor) +
                    12 * (size_t)height * width * sizeof(double));
     PAPOF_TRY(S.rc);
     std::vector<double> host(np * 6);
@@ -1421,22 +1429,35 @@ int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_m
     hipEventDestroy(e1);
     if (sor_mode == PAPOF_SOR_EXACT) PAPOF_TRY(sor_check(h));
     *ms_per_solve = (double)ms / reps;
-    if (std::getenv("PAPOF_SOR_DBG") && sor_mode == PAPOF_SOR_EXACT && sp.sd.group > 1) {  // per-task wait statistics
+    if (std::getenv("PAPOF_SOR_DBG") && sor_mode == PAPOF_SOR_EXACT && sp.sd.fuse == 1) {  // per-task statistics
         const size_t ntask = (size_t)sp.sd.nb * n_sor;
-        PAPOF_HIP(hipMalloc((void**)&h->sor_dbg, ntask * 4 * sizeof(unsigned long long)));
-        PAPOF_HIP(hipMemset(h->sor_dbg, 0, ntask * 4 * sizeof(unsigned long long)));
+        PAPOF_HIP(hipMalloc((void**)&h->sor_dbg, ntask * 8 * sizeof(unsigned long long)));
+        PAPOF_HIP(hipMemset(h->sor_dbg, 0, ntask * 8 * sizeof(unsigned long long)));
         PAPOF_TRY(sor_solve(h, sp, height, width, 0.012, 1.8, n_sor, sor_mode));
         PAPOF_HIP(hipStreamSynchronize(h->stream));
-        std::vector<unsigned long long> st(ntask * 4);
+        std::vector<unsigned long long> st(ntask * 8);
         PAPOF_HIP(hipMemcpy(st.data(), h->sor_dbg, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         hipFree(h->sor_dbg);
         h->sor_dbg = nullptr;
-        for (int k = 0; k < n_sor && k < 8; k++)
-            for (int b = 0; b < sp.sd.nb && b < 3; b++) {
-                const unsigned long long* o = &st[((size_t)k * sp.sd.nb + b) * 4];
-                std::fprintf(stderr, "[sor dbg] sweep %2d band %2d: total %8.1f us  wait_covered %7.1f  lds_in %7.1f  lds_out %7.1f\n",
-                             k, b, o[0] / 2400.0, o[1] / 2400.0, o[2] / 2400.0, o[3] / 2400.0);
-            }
+        if (sp.sd.group > 1) {
+            for (int k = 0; k < n_sor && k < 8; k++)
+                for (int b = 0; b < sp.sd.nb && b < 3; b++) {
+                    const unsigned long long* o = &st[((size_t)k * sp.sd.nb + b) * 4];
+                    std::fprintf(stderr, "[sor dbg] sweep %2d band %2d: total %8.1f us  wait_covered %7.1f  lds_in %7.1f  lds_out %7.1f\n",
+                                 k, b, o[0] / 2400.0, o[1] / 2400.0, o[2] / 2400.0, o[3] / 2400.0);
+                }
+        } else {  // k_sor_exact: time line of every task, us since the first task entered (s_memrealtime = 100 MHz)
+            unsigned long long t0 = ~0ull;
+            for (size_t t = 0; t < ntask; t++)
+                if (st[t * 8]) t0 = std::min(t0, st[t * 8]);
+            for (int k = 0; k < n_sor && k < 10; k++)
+                for (int b = 0; b < sp.sd.nb && b < 3; b++) {
+                    const unsigned long long* o = &st[((size_t)k * sp.sd.nb + b) * 8];
+                    std::fprintf(stderr, "[sor dbg] sweep %2d band %2d: entry %7.2f  covered %7.2f  iter0 %7.2f  iter1 %7.2f  iter2 %7.2f  iter3 %7.2f  end %8.2f\n",
+                                 k, b, (o[0] - t0) * 0.01, (o[1] - t0) * 0.01, (o[2] - t0) * 0.01, (o[3] - t0) * 0.01,
+                                 (o[4] - t0) * 0.01, (o[5] - t0) * 0.01, (o[6] - t0) * 0.01);
+                }
+        }
     }
     return PAPOF_OK;
 }

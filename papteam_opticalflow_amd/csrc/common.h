@@ -111,22 +111,50 @@ struct SkewDims {
                  // in one workgroup, handed from wave to wave through LDS (sor.hip); the planes then alternate per GROUP
     int dpar;    // which plane holds the values of the last sweep
     size_t nh;   // grouped solver: cells of the halo rows H[sweep][band][position] that follow the two planes
+    int fuse;    // sweeps per WAVE: 1, or 2 = k_sor_fused (two consecutive sweeps of a band in one wavefront, the second
+                 // two steps behind the first, fed from registers); bands then have 61 rows and climb two rows per pair
+    int band_rows, koff, poff;  // where (du, dv)(i, j) sits after the last sweep: t = i + koff, band t / band_rows,
+                                // cell c = 1 + t % band_rows, position j + c + poff (kernels.hip: dudv_cell)
 };
-inline SkewDims skew_dims(int h, int w, int n_sor, int group = 1) {
+constexpr int kFusedRows = kLanes - 3;  // fused pairs: lanes 2..62 real in the first sweep, lanes 1..61 in the second
+inline SkewDims skew_dims(int h, int w, int n_sor, int group = 1, int fuse = 1) {
     SkewDims d;
-    d.nb = (h + n_sor - 1 + kBandRows - 1) / kBandRows;
+    d.fuse = (fuse == 2 && group <= 1) ? 2 : 1;
+    d.group = d.fuse == 2 ? 1 : (group < 1 ? 1 : group);
     d.ns = w + kLanes - 1;
-    d.rt = d.qt = n_sor + 1;
-    d.hp = (d.rt + kBandRows * d.nb + 2 + 7) / 8 * 8;
-    d.npos = d.qt + d.ns + 2 * kSorMaxDepth + 2 + kBandRows * (d.nb - 1) + 2;
-    d.n = (size_t)d.npos * d.hp;
     d.n_sor = n_sor;
     d.npos_d = d.ns + 2 * kSorMaxDepth + 72;  // every position a task can touch, prefetch beyond the last step included
+    if (d.fuse == 2) {
+        const int last = (n_sor + 1) / 2 - 1;  // index of the last pair of sweeps
+        d.band_rows = kFusedRows;
+        d.nb = (h + 2 * last + 1 + kFusedRows - 1) / kFusedRows;
+        d.rt = d.qt = n_sor + 3;
+        d.hp = (d.rt + kFusedRows * d.nb + 4 + 7) / 8 * 8;
+        d.npos = d.qt + d.ns + 2 * kSorMaxDepth + 2 + kFusedRows * (d.nb - 1) + 2;
+        d.dpar = last & 1;
+        d.koff = 2 * last + 1;
+        d.poff = 3;
+        d.nh = 0;
+    } else {
+        d.band_rows = kBandRows;
+        d.nb = (h + n_sor - 1 + kBandRows - 1) / kBandRows;
+        d.rt = d.qt = n_sor + 1;
+        d.hp = (d.rt + kBandRows * d.nb + 2 + 7) / 8 * 8;
+        d.npos = d.qt + d.ns + 2 * kSorMaxDepth + 2 + kBandRows * (d.nb - 1) + 2;
+        d.dpar = d.group == 1 ? ((n_sor - 1) & 1) : (((n_sor + d.group - 1) / d.group - 1) & 1);
+        d.koff = n_sor - 1;
+        d.poff = 1;
+        d.nh = d.group == 1 ? 0 : (size_t)n_sor * d.nb * d.npos_d;
+    }
+    d.n = (size_t)d.npos * d.hp;
     d.nd = (size_t)2 * d.npos_d * d.nb * kLanes;
-    d.group = group < 1 ? 1 : group;
-    d.dpar = d.group == 1 ? ((n_sor - 1) & 1) : (((n_sor + d.group - 1) / d.group - 1) & 1);
-    d.nh = d.group == 1 ? 0 : (size_t)n_sor * d.nb * d.npos_d;
     return d;
+}
+// capacity of one level's operand planes: the larger of the layouts the solver may bind (sor_bind)
+inline void skew_capacity(int h, int w, int n_sor, size_t& cells, size_t& cells_d) {
+    const SkewDims a = skew_dims(h, w, n_sor, 2), b = skew_dims(h, w, n_sor, 1, 2);
+    cells = a.n > b.n ? a.n : b.n;
+    cells_d = (a.nd + a.nh) > (b.nd + b.nh) ? (a.nd + a.nh) : (b.nd + b.nh);
 }
 
 // SOR operands of one solve.  `skew` selects the layout of all eight planes:
@@ -214,6 +242,7 @@ struct papof_handle {
     bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
     int sor_depth = 0;               // software-pipeline depth R (steps) of the exact-order SOR kernel; 0 = by level size
     unsigned long long* sor_dbg = nullptr;  // device buffer for per-task wait statistics (PAPOF_SOR_DBG)
+    int sor_fuse = 0;                // sweeps per wave of the exact-order solver: 1 or 2; 0 = by default (2 with DPP)
     int sor_group = 0;               // consecutive sweeps of a band per workgroup: 1, 2 or 4; 0 = by problem size
     // second stream for everything that does not depend on the flow (pyramids, features, smoothed frame 1 of every
     // level, derivative planes of the final bicubic warp): runs beside the coarse levels' latency-bound solves

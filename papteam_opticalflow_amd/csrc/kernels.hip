@@ -249,8 +249,9 @@ __global__ __launch_bounds__(256) void k_smooth_hv_blend(const double* __restric
 // (du,dv) interleaved, cell (i, j) at (i + j + qt) * hp + (i + rt) -- see common.h.
 struct SkewIdx {
     int hp, qt, rt;        // coefficient planes
-    int nb, npos_d, klast; // (du, dv) planes: bands, positions, index of the last sweep
+    int nb, npos_d;        // (du, dv) planes: bands, positions
     int dpar;              // which of the two (du, dv) planes holds the last sweep's values
+    int band_rows, koff, poff;  // rows per band, climb of the bands up to the last sweep, position offset (common.h)
 };
 __device__ __forceinline__ size_t skew_cell(int i, int j, const SkewIdx& k) {
     return (size_t)(i + j + k.qt) * k.hp + (size_t)(i + k.rt);
@@ -262,9 +263,9 @@ __device__ __forceinline__ size_t sor_index(int i, int j, int W, const SkewIdx& 
 }
 // cell of (du, dv)(i, j) after the last sweep in the banded ping-pong planes (common.h)
 __device__ __forceinline__ size_t dudv_cell(int i, int j, const SkewIdx& k) {
-    const int t = i + k.klast, b = t / kBandRows, c = 1 + (t - b * kBandRows);
+    const int t = i + k.koff, b = t / k.band_rows, c = 1 + (t - b * k.band_rows);
     const size_t parity = (size_t)k.dpar * k.npos_d * k.nb * kLanes;
-    return parity + ((size_t)(j + c + 1) * k.nb + b) * kLanes + c;
+    return parity + ((size_t)(j + c + k.poff) * k.nb + b) * kLanes + c;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -908,7 +909,7 @@ int smooth_v_blend(papof_handle* h, const double* tmp, const double* im1s, doubl
 }
 
 static SkewIdx skew_idx(const SorPlanes& sp) {
-    return SkewIdx{sp.sd.hp, sp.sd.qt, sp.sd.rt, sp.sd.nb, sp.sd.npos_d, sp.sd.n_sor - 1, sp.sd.dpar};
+    return SkewIdx{sp.sd.hp, sp.sd.qt, sp.sd.rt, sp.sd.nb, sp.sd.npos_d, sp.sd.dpar, sp.sd.band_rows, sp.sd.koff, sp.sd.poff};
 }
 
 // `prev` = operands of the previous inner iteration's solve (nullptr in the first one: du = dv = 0)

@@ -41,7 +41,7 @@
 //     * all nb * n_sor tasks are launched at once (one 64-thread workgroup each; a few hundred waves, all
 //       co-resident) and pipeline through per-task progress counters (one 128-byte line each).  Before issuing the
 //       loads of steps < e a task waits for
-//           prog[k-1][b]   >= min(NS, e + 1)      own band, previous sweep
+//           prog[k-1][b]   >= min(NS, e)          own band, previous sweep (its step s wrote what our step s reads)
 //           prog[k][b-1]   >= min(NS, e + 63)     band above, this sweep (ghost lane 0)
 //           prog[k-2][b+1] >= min(NS, e - 62)     band below, two sweeps ago (write-after-read of our block)
 //       A waiter only ever waits on lower block indices.  tests/sim_sor_wave.py executes this exact dataflow under
@@ -58,6 +58,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 
@@ -76,6 +77,7 @@ struct ExactArgs {
     int H, W, nb, ns, hp, npos, qt, rt, npos_d, n_sor;
     int xcd_affine;
     double nalpha, om1;
+    unsigned long long* dbg;  // diagnostics (PAPOF_SOR_DBG): per task 8 time stamps (s_memrealtime, 100 MHz), else null
 };
 
 __device__ __forceinline__ double ld_agent(const double* p) {
@@ -187,7 +189,15 @@ struct Slots {
 
 struct Task {  // wave-uniform task constants (SGPRs)
     __amdgpu_buffer_rsrc_t ra, rb, rc, rd;  // descriptors of the four paired planes
+    __amdgpu_buffer_rsrc_t rp;              // the progress counters (k_sor_exact / k_sor_fused)
 };
+
+// Publication of a task's progress WITHOUT a branch: every lane executes the store, the per-lane offset is out of
+// range for all lanes but lane 0 (dropped).  An `if (lane == 0)` is a divergent branch, and one divergent branch inside
+// the sweep loop makes the compiler structurise the whole loop, the scalar early exits included (see uni() below).
+__device__ __forceinline__ void publish(const Task& T, unsigned lane_off, unsigned steps) {
+    __builtin_amdgcn_raw_buffer_store_b32(steps, T.rp, lane_off, 0, 16 /* sc1 */);
+}
 
 // Per-lane ABSOLUTE byte offsets (constant VGPRs); the step index enters only through uniform soffsets
 // (s * pos_c for the coefficient planes, s * pos_d for the unknowns).  kOob switches an access off (reads 0.0)
@@ -324,25 +334,45 @@ __device__ __forceinline__ Polls poll(const Deps& d) {
     p.dn2 = d.has_dn2 ? __hip_atomic_load(d.dn2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
     return p;
 }
-// May every load that touches steps < s_end be issued?  (see the dependency table in the file header)
+// The progress values and the markers are wave-uniform by construction (every lane loads the same word).  Reading them
+// through v_readfirstlane makes the branches on them SCALAR: the compiler then keeps real early exits instead of
+// structurising them into exec-masked paths that rejoin the sweep loop -- along those phantom paths a slot refilled a
+// few instructions earlier would reach its next use, and the waitcnt insertion pass answered with `s_waitcnt vmcnt(0)`
+// at the top of every iteration (a full drain of the operand pipeline, ~0.06 us per step).
+__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ Polls uni(const Polls& p) { return Polls{uni(p.own), uni(p.up), uni(p.dn2)}; }
+
+// May every load that touches steps < s_end be issued?  (see the dependency tables in the file header; UP = how far the
+// ghost lanes read ahead in the band above: 63 steps in k_sor_exact, 64 in k_sor_fused; OWN = 0 / 1 likewise for the
+// own band's previous sweep / pair)
+template <int OWN, int UP>
 __device__ __forceinline__ bool covered(const Polls& p, int ns, int s_end) {
-    return p.own >= (unsigned)min(ns, s_end + 1) && p.up >= (unsigned)min(ns, s_end + 63) &&
+    return p.own >= (unsigned)min(ns, s_end + OWN) && p.up >= (unsigned)min(ns, s_end + UP) &&
            p.dn2 >= (unsigned)min(ns, max(0, s_end - 62));
 }
 
-// Bounded wave-uniform wait until the producers cover steps < s_end.  false = abort / timeout.
-__device__ __forceinline__ bool wait_covered(const ExactArgs& A, Polls& pl, const Deps& d, int s_end) {
-    unsigned spins = 0;
-    while (!covered(pl, A.ns, s_end)) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 255u) == 0u) {
-            if (__hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            if (spins > kSpinLimit) {
-                __hip_atomic_store(A.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
+// Bounded wave-uniform wait until the producers cover steps < s_end.  false = abort / timeout.  The fast path consumes
+// the poll that was issued an iteration earlier (an in-order wait on that poll only); the slow path polls afresh.
+// A task that sees the abort word (or gives up) simply ENDS (s_endpgm): an early `return` out of the sweep loop would
+// again be merged into the loop's latch block by the compiler (same phantom paths as above).
+__device__ __forceinline__ void end_task() { __builtin_amdgcn_endpgm(); }
+
+template <int OWN, int UP>
+__device__ __forceinline__ bool wait_covered(const ExactArgs& A, const Polls& pl, const Deps& d, int s_end) {
+    Polls p = uni(pl);
+    if (!covered<OWN, UP>(p, A.ns, s_end)) {
+        unsigned spins = 0;
+        do {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255u) == 0u) {
+                if (uni(__hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) return false;
+                if (spins > kSpinLimit) {
+                    __hip_atomic_store(A.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
             }
-        }
-        pl = poll(d);
+            p = uni(poll(d));
+        } while (!covered<OWN, UP>(p, A.ns, s_end));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler-only: keep the loads below the polls
     return true;
@@ -377,6 +407,8 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     }
     const int ns = A.ns;
     const bool ghost = lane == 0 || lane == kLanes - 1;
+    unsigned long long* const dbg = A.dbg ? A.dbg + (size_t)(k * A.nb + b) * 8 : nullptr;  // every lane stores the same
+    if (dbg) dbg[0] = __builtin_amdgcn_s_memrealtime();
     Task T;
     const unsigned plane_bytes = (unsigned)(((size_t)A.npos * A.hp + kLanes) * 16u);
     constexpr unsigned kBlock = kLanes * 16u;                                  // one task's cells of one position
@@ -396,14 +428,17 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     // (du, dv): the writer of step s uses position s + 1 (position 0 is never written: the centre before step 0)
     const unsigned mine = (unsigned)(k & 1) * par_bytes, prev = (unsigned)((k + 1) & 1) * par_bytes;
     L.st = mine + L.pos_d + (unsigned)b * kBlock + lane * 16u;
-    L.pd = prev + L.pos_d + (unsigned)b * kBlock + (lane - 1u) * 16u;  // lanes >= 1: own block, cell lane - 1
-    if (lane == 0)  // the row above, NEW value: block b-1, cell 62, written by (b-1, k) 63 steps ahead of ours
-        L.pd = b > 0 ? mine + 64u * L.pos_d + (unsigned)(b - 1) * kBlock + 62u * 16u : kOob;
+    // lanes >= 1: own block, cell lane - 1; lane 0: the row above, NEW value: block b-1, cell 62, written by (b-1, k) 63
+    // steps ahead of ours.  (Selects, not branches: a divergent branch anywhere makes the compiler structurise the kernel.)
+    const unsigned pd_above = b > 0 ? mine + 64u * L.pos_d + (unsigned)(b - 1) * kBlock + 62u * 16u : kOob;
+    L.pd = lane == 0 ? pd_above : prev + L.pos_d + (unsigned)b * kBlock + (lane - 1u) * 16u;
     const double om1 = ghost ? 1.0 : A.om1;  // ghost lanes pass their centre value through unchanged
 
     // one 128-byte line per counter: hundreds of waves publish and poll concurrently, and counters sharing a
     // line would serialise at the memory side
-    unsigned* const my_prog = A.prog + ((size_t)k * A.nb + b) * kProgStride;
+    const unsigned prog_bytes = (unsigned)A.n_sor * (unsigned)A.nb * kProgStride * 4u;
+    T.rp = __builtin_amdgcn_make_buffer_rsrc((void*)A.prog, 0, prog_bytes, 0x00020000);
+    const unsigned my_prog = lane == 0 ? (unsigned)(k * A.nb + b) * kProgStride * 4u : kOob;
     Deps D;
     D.has_own = k > 0;
     D.has_up = b > 0;
@@ -421,16 +456,21 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     // loads of steps < (i + 2) R; its coverage check uses a poll that was itself issued one iteration earlier
     // (consuming a poll forces an in-order vmcnt wait on every older load, so finer-grained polling stalls).
     // The coefficient operands depend on nobody: their first R steps are requested before the task waits.
+    // Start-up in two stages: the first R steps' unknowns are requested as soon as the producers cover THEM; the check
+    // for the next R steps (the refills of iteration 0) is made with a fresh poll at the start of iteration 0, while those
+    // first loads are in flight -- a hand-off then costs R steps and one load latency less than waiting for 2R up front.
     Unroll<R, R - 1, DPP>::fill_coef(T, L, c);
     Polls pl = poll(D);
-    if (!wait_covered(A, pl, D, 2 * R)) return;
+    if (!wait_covered<0, 63>(A, pl, D, R)) end_task();
     {  // centre of the first cells = the right-old of "step -1" (position 0: zero; lane 0: position 63 above)
         const unsigned first = L.pd == kOob ? kOob : L.pd - L.pos_d;
         const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, first, 0, kAuxSc1));
         S.duC = c0.x;
         S.dvC = c0.y;
     }
+    if (dbg) dbg[1] = __builtin_amdgcn_s_memrealtime();
     Unroll<R, R - 1, DPP>::fill_unknowns(T, L, c);
+    pl = poll(D);
 
     // MARKER loads: a 4-byte load issued right after the store of some step retires (vmcnt is in order) only after
     // that store has completed, so consuming it a few steps later proves the step complete and lets the task
@@ -443,8 +483,8 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     unsigned ma = 0u, mb = 0u;
     // one iteration = R steps; `i` is only used for step numbers.  The first iteration is peeled off the loop so that the
     // loop header joins two states with the same pipeline contents (after an iteration / after an iteration).
-    const auto iteration = [&](int i, bool first) -> bool {
-        if (!first && !wait_covered(A, pl, D, (i + 2) * R)) return false;
+    const auto iteration = [&](int i, bool first) {
+        if (!wait_covered<0, 63>(A, pl, D, (i + 2) * R)) end_task();
         // The poll for the next iteration's check is consumed at the start of the next iteration, where it waits (in
         // order) for every load issued before it.  Issued in the middle of this iteration it is half an iteration fresher
         // (a shorter hand-off) but then waits for the refills of the first half: at R = 10 those are 5 steps old and long
@@ -458,10 +498,8 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
         Seg<R, 0, CA, DPP>::run(A, T, L, om1, i * R, c, S);
         if (!first) {  // marker A of the previous iteration: its steps < (i-1)R + H are complete
             asm volatile("" ::"v"(ma), "v"(S.duL), "v"(S.dvL) : "memory");
-            if (ma != 0u) return false;
-            if (lane == 0)
-                __hip_atomic_store(my_prog, (unsigned)min(ns, (i - 1) * R + H), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (uni(ma) != 0u) end_task();
+            publish(T, my_prog, (unsigned)min(ns, (i - 1) * R + H));
         }
         Seg<R, CA, H, DPP>::run(A, T, L, om1, i * R, c, S);
         ma = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // marker A: after step H - 1
@@ -469,21 +507,271 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
         Seg<R, H, CB, DPP>::run(A, T, L, om1, i * R, c, S);
         if (!first) {  // marker B of the previous iteration: steps < i R are complete
             asm volatile("" ::"v"(mb), "v"(S.duL), "v"(S.dvL) : "memory");
-            if (mb != 0u) return false;
-            if (lane == 0)
-                __hip_atomic_store(my_prog, (unsigned)min(ns, i * R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (uni(mb) != 0u) end_task();
+            publish(T, my_prog, (unsigned)min(ns, i * R));
         }
         Seg<R, CB, R, DPP>::run(A, T, L, om1, i * R, c, S);
         mb = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // marker B: after step R - 1
         pl = pn;
-        return true;
     };
-    if (!iteration(0, true)) return;
-    for (int i = 1; i < n_iter; ++i)
-        if (!iteration(i, false)) return;
+    iteration(0, true);
+    if (dbg) dbg[2] = __builtin_amdgcn_s_memrealtime();
+    for (int i = 1; i < n_iter; ++i) {
+        iteration(i, false);
+        if (dbg && i < 4) dbg[2 + i] = __builtin_amdgcn_s_memrealtime();
+    }
     // final publication: every store of this wave has left the CU before the counter moves (guide G16/R1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(my_prog, (unsigned)ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    publish(T, my_prog, (unsigned)ns);
+    if (dbg) dbg[6] = __builtin_amdgcn_s_memrealtime();
+}
+
+// ------------------------------------------------------------------------------------------------
+// FUSED PAIRS: two consecutive sweeps of a band in ONE wavefront (temporal blocking in registers).
+//
+// Task (band b, pair q) runs sweeps k = 2q and k + 1.  Lane l stands for image row r0 + l, r0 = 61b - 2q - 2, in BOTH
+// sweeps; at step s the first sweep updates column s - l (exactly as k_sor_exact), the second sweep column s - l - 2:
+// everything the second sweep needs from the first -- centre (r, j), right (r, j+1), down (r+1, j) at sweep k -- was
+// produced one / two steps earlier by this lane or by lane l + 1, so it is taken from registers; the coefficient cells
+// of step s - 2 are simply kept two steps longer (their slot is refilled after the second sweep has used it).  The two
+// updates of a step are independent chains, so the wave issues them interleaved: a step costs little more than one
+// sweep's, but moves the memory operations of ONE sweep (4 loads + 1 store) for TWO sweeps of work, and the number of
+// sweep-to-sweep hand-offs through memory halves.
+//   lanes, first sweep:   0 carrier (below)   1 ghost: row above, sweep k      2..62 real (61 rows)   63 ghost: row below
+//   lanes, second sweep:  0 ghost: row above, sweep k+1      1..61 real (the same 61 rows + 1 = bands climb two rows
+//                         per pair)            62 its first-sweep value IS the row below at sweep k    63 unused
+//   lane 0 is a pass-through in both sweeps: it loads the sweep-(k+1) values of its row (written by the band above) as
+//   its first-sweep "right" operand, hands them unchanged to its second sweep, and lane 1 reads them there as up-new.
+// One store per step: lanes 0..61 their second-sweep result, lane 62 its FIRST-sweep result (the band below needs
+// that row at sweep k: its lane 1), lane 63 nothing.  Planes alternate per pair.  With an odd sweep count the last
+// pair's second sweep is the identity (compile-time variant), so the result layout does not depend on parity.
+// Dependencies of (b, q), in completed steps, before the loads of steps < e are issued:
+//     prog[q-1][b]   >= min(NS, e + 1)     own band, previous pair (lane l reads its cell l - 2 at position s + 2)
+//     prog[q][b-1]   >= min(NS, e + 64)    band above, this pair (lane 1: cell 62 at position s + 63, lane 0: cell 61
+//                                          at position s + 65)
+//     prog[q-2][b+1] >= min(NS, e - 62)    band below, two pairs ago (write-after-read of cells 61 / 62 of our block)
+// ------------------------------------------------------------------------------------------------
+struct FLane {       // per-lane constants of the fused kernel (VGPRs)
+    unsigned m1;     // first sweep: all ones where the lane is real (2..62), else 0 -> a1 = a2 = 0 -> pass-through
+    double om1a;     // 1 - omega of the first sweep (1.0 on ghost lanes)
+    double om1b;     // ... of the second sweep
+    bool first_out;  // lane 62: stores its first-sweep result
+};
+
+template <int R, int t, bool DPP, bool SKIP2, bool ID2>
+__device__ __forceinline__ void f_step(const ExactArgs& A, const Task& T, const LaneOffs& L, const FLane& F, int s,
+                                       Slots<R>& c, State& S1, State& S2) {
+    const double nalpha = A.nalpha;
+    constexpr int t2 = (t + R - 2) % R;  // slot holding the coefficient cells of step s - 2
+    // ---- second sweep, column s - l - 2: operands are the first sweep's results of steps s - 2 (centre) and s - 1
+    const double duR2 = S1.duL, dvR2 = S1.dvL;
+    double duN2, dvN2;
+    if (SKIP2) {  // steps 0 and 1: every lane is still left of column 0
+        duN2 = 0.0;
+        dvN2 = 0.0;
+    } else if (ID2) {
+        duN2 = S2.duC;
+        dvN2 = S2.dvC;
+    } else {
+        const D2 qa = as_d2(c.pa[t2]), qb = as_d2(c.pb[t2]), qc = as_d2(c.pc[t2]);
+        const double phiC = qa.x, xy = qa.y;
+        const double duU = from_above<DPP>(S2.duL);
+        const double dvU = from_above<DPP>(S2.dvL);
+        const double phiU = from_above<DPP>(S2.phiL);
+        const double duD = from_below<DPP>(duR2);
+        const double dvD = from_below<DPP>(dvR2);
+        double s1 = S2.phiL * S2.duL;
+        double s2 = S2.phiL * S2.dvL;
+        s1 += phiC * duR2;
+        s2 += phiC * dvR2;
+        s1 += phiU * duU;
+        s2 += phiU * dvU;
+        s1 += phiC * duD;
+        s2 += phiC * dvD;
+        s1 *= nalpha;
+        s2 *= nalpha;
+        s1 += xy * S2.dvC;
+        duN2 = F.om1b * S2.duC + qb.x * (qc.x - s1);
+        s2 += xy * duN2;
+        dvN2 = F.om1b * S2.dvC + qb.y * (qc.y - s2);
+        S2.phiL = moved(phiC);
+    }
+    // ---- first sweep, column s - l (as k_sor_exact::step, with the per-lane ghost mask on (a1, a2))
+    const D2 pa = as_d2(c.pa[t]), pc = as_d2(c.pc[t]), pd = as_d2(c.pd[t]);
+    const u32x4 pbm = c.pb[t] & u32x4{F.m1, F.m1, F.m1, F.m1};
+    const D2 pb = as_d2(pbm);
+    const double phiC = pa.x, xy = pa.y, duR = pd.x, dvR = pd.y;
+    const double duU = from_above<DPP>(S1.duL);
+    const double dvU = from_above<DPP>(S1.dvL);
+    const double phiU = from_above<DPP>(S1.phiL);
+    const double duD = from_below<DPP>(duR);
+    const double dvD = from_below<DPP>(dvR);
+    double s1 = S1.phiL * S1.duL;
+    double s2 = S1.phiL * S1.dvL;
+    s1 += phiC * duR;
+    s2 += phiC * dvR;
+    s1 += phiU * duU;
+    s2 += phiU * dvU;
+    s1 += phiC * duD;
+    s2 += phiC * dvD;
+    s1 *= nalpha;
+    s2 *= nalpha;
+    s1 += xy * S1.dvC;
+    const double duN = F.om1a * S1.duC + pb.x * (pc.x - s1);
+    s2 += xy * duN;
+    const double dvN = F.om1a * S1.dvC + pb.y * (pc.y - s2);
+    const double o1 = F.first_out ? duN : duN2, o2 = F.first_out ? dvN : dvN2;
+    __builtin_amdgcn_raw_buffer_store_b128(as_u4(o1, o2), T.rd, L.st, (unsigned)s * L.pos_d, kAuxSc1);
+    S2.duL = duN2;
+    S2.dvL = dvN2;
+    S2.duC = duR2;
+    S2.dvC = dvR2;
+    S1.duL = duN;
+    S1.dvL = dvN;
+    S1.phiL = phiC;  // its slot lives two more steps
+    S1.duC = moved(duR);
+    S1.dvC = moved(dvR);
+    asm volatile("" ::: "memory");  // keep this step's store ahead of its refill loads in the instruction stream
+    load_unknowns<R, t>(T, L, s + R, c);
+    if (!SKIP2) load_coef<R, t2>(T, L, s - 2 + R, c);  // the slot of step s - 2 is free now
+}
+
+template <int R, int t0, int t1, bool DPP, bool FIRST, bool ID2>
+struct FSeg {
+    static __device__ __forceinline__ void run(const ExactArgs& A, const Task& T, const LaneOffs& L, const FLane& F,
+                                               int s0, Slots<R>& c, State& S1, State& S2) {
+        f_step<R, t0, DPP, FIRST && t0 < 2, ID2>(A, T, L, F, s0 + t0, c, S1, S2);
+        FSeg<R, t0 + 1, t1, DPP, FIRST, ID2>::run(A, T, L, F, s0, c, S1, S2);
+    }
+};
+template <int R, int t1, bool DPP, bool FIRST, bool ID2>
+struct FSeg<R, t1, t1, DPP, FIRST, ID2> {
+    static __device__ __forceinline__ void run(const ExactArgs&, const Task&, const LaneOffs&, const FLane&, int,
+                                               Slots<R>&, State&, State&) {}
+};
+
+template <int R, bool DPP, bool ID2>
+__device__ __forceinline__ void f_run(const ExactArgs& A, const Task& T, const LaneOffs& L, const FLane& F,
+                                      const Deps& D, unsigned my_prog) {
+    const int ns = A.ns;
+    const int n_iter = (ns + R - 1) / R;
+    State S1, S2;
+    S1.duL = S1.dvL = S1.phiL = 0.0;
+    S2.duL = S2.dvL = S2.phiL = S2.duC = S2.dvC = 0.0;
+    Slots<R> c;
+    Unroll<R, R - 1, DPP>::fill_coef(T, L, c);
+    Polls pl = poll(D);
+    if (!wait_covered<1, 64>(A, pl, D, R)) end_task();  // staged start-up, see k_sor_exact
+    {  // centre of the first cells = the right operand of "step -1"
+        const unsigned first = L.pd == kOob ? kOob : L.pd - L.pos_d;
+        const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, first, 0, kAuxSc1));
+        S1.duC = c0.x;
+        S1.dvC = c0.y;
+    }
+    Unroll<R, R - 1, DPP>::fill_unknowns(T, L, c);
+    pl = poll(D);
+    // markers, polls and the peeled first iteration: exactly as in k_sor_exact (see there)
+    constexpr int H = R / 2, DM = R >= 6 ? R - 3 : H;
+    constexpr int CA = H + DM - R, CB = DM;
+    static_assert(CA >= 0 && CA < H && CB >= H && CB < R, "marker consumption points");
+    unsigned ma = 0u, mb = 0u;
+    const auto iteration = [&](int i, auto first_c) {
+        constexpr bool first = decltype(first_c)::value;
+        if (!wait_covered<1, 64>(A, pl, D, (i + 2) * R)) end_task();
+        constexpr bool kMidPoll = R >= 10;
+        Polls pn{0u, 0u, 0u};
+        if (!kMidPoll) pn = poll(D);
+        FSeg<R, 0, CA, DPP, first, ID2>::run(A, T, L, F, i * R, c, S1, S2);
+        if (!first) {
+            asm volatile("" ::"v"(ma), "v"(S1.duL), "v"(S1.dvL) : "memory");
+            if (uni(ma) != 0u) end_task();
+            publish(T, my_prog, (unsigned)min(ns, (i - 1) * R + H));
+        }
+        FSeg<R, CA, H, DPP, first, ID2>::run(A, T, L, F, i * R, c, S1, S2);
+        ma = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // marker A: after step H - 1
+        if (kMidPoll) pn = poll(D);
+        FSeg<R, H, CB, DPP, first, ID2>::run(A, T, L, F, i * R, c, S1, S2);
+        if (!first) {
+            asm volatile("" ::"v"(mb), "v"(S1.duL), "v"(S1.dvL) : "memory");
+            if (uni(mb) != 0u) end_task();
+            publish(T, my_prog, (unsigned)min(ns, i * R));
+        }
+        FSeg<R, CB, R, DPP, first, ID2>::run(A, T, L, F, i * R, c, S1, S2);
+        mb = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // marker B: after step R - 1
+        pl = pn;
+    };
+    iteration(0, std::true_type{});
+    for (int i = 1; i < n_iter; ++i) iteration(i, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    publish(T, my_prog, (unsigned)ns);
+}
+
+template <int R, bool DPP>
+__global__ __launch_bounds__(64) void k_sor_fused(ExactArgs A) {
+    static_assert(R >= 6 && R % 2 == 0, "two markers per iteration; coefficient slots live two extra steps");
+    const unsigned lane = threadIdx.x;
+    const int pairs = (A.n_sor + 1) >> 1;
+    int q, b;
+    if (A.xcd_affine) {  // as k_sor_exact: all pairs of a band on one XCD (<= 8 bands)
+        const int nf = A.nb >> 3, rem = A.nb & 7, S = 8 * nf + (rem ? 8 : 0);
+        q = blockIdx.x / S;
+        const int r = blockIdx.x - q * S;
+        if (r < 8 * nf) {
+            b = r;
+        } else {
+            const int j = r - 8 * nf - (nf ? q % (9 - rem) : 0);
+            if (j < 0 || j >= rem) return;
+            b = 8 * nf + j;
+        }
+    } else {
+        q = blockIdx.x / A.nb;
+        b = blockIdx.x - q * A.nb;
+    }
+    Task T;
+    const unsigned plane_bytes = (unsigned)(((size_t)A.npos * A.hp + kLanes) * 16u);
+    constexpr unsigned kBlock = kLanes * 16u;
+    const unsigned par_bytes = (unsigned)A.npos_d * (unsigned)A.nb * kBlock;
+    T.ra = __builtin_amdgcn_make_buffer_rsrc((void*)A.phi, 0, plane_bytes, 0x00020000);
+    T.rb = __builtin_amdgcn_make_buffer_rsrc((void*)A.a1, 0, plane_bytes, 0x00020000);
+    T.rc = __builtin_amdgcn_make_buffer_rsrc((void*)A.b1, 0, plane_bytes, 0x00020000);
+    T.rd = __builtin_amdgcn_make_buffer_rsrc((void*)A.du, 0, 2u * par_bytes, 0x00020000);
+    const int r0 = kFusedRows * b - 2 * q - 2;  // image row of lane 0
+    LaneOffs L;
+    L.pos_c = (unsigned)A.hp * 16u;
+    L.pos_d = (unsigned)A.nb * kBlock;
+    const unsigned base = ((unsigned)(r0 + A.qt) * (unsigned)A.hp + (unsigned)(r0 + A.rt) + lane) * 16u;
+    L.pa = base;
+    L.pbc = (lane == 0 || lane == kLanes - 1) ? kOob : base;
+    const unsigned mine = (unsigned)(q & 1) * par_bytes, prev = (unsigned)((q + 1) & 1) * par_bytes;
+    L.st = lane == kLanes - 1 ? kOob : mine + L.pos_d + (unsigned)b * kBlock + lane * 16u;  // step s -> position s + 1
+    // first-sweep right operand of step s: the previous pair's cell lane - 2 at position s + 2 (the band climbed two rows)
+    // lane 1: row above at sweep k = first-sweep result of lane 62 of (b-1, q), stored at its step s + 62;
+    // lane 0: row above that at sweep k+1 = second-sweep result of lane 61 of (b-1, q), stored at its step s + 64
+    const unsigned pd1 = b > 0 ? mine + 63u * L.pos_d + (unsigned)(b - 1) * kBlock + 62u * 16u : kOob;
+    const unsigned pd0 = b > 0 ? mine + 65u * L.pos_d + (unsigned)(b - 1) * kBlock + 61u * 16u : kOob;
+    const unsigned pd_own = prev + 2u * L.pos_d + (unsigned)b * kBlock + (lane - 2u) * 16u;
+    L.pd = lane == 0 ? pd0 : (lane == 1 ? pd1 : pd_own);
+    FLane F;
+    const bool real1 = lane >= 2 && lane <= kLanes - 2;
+    F.m1 = real1 ? 0xffffffffu : 0u;
+    F.om1a = real1 ? A.om1 : 1.0;
+    F.om1b = (lane == 0 || lane == kLanes - 1) ? 1.0 : A.om1;
+    F.first_out = lane == kLanes - 2;
+
+    const unsigned prog_bytes = (unsigned)A.n_sor * (unsigned)A.nb * kProgStride * 4u;
+    T.rp = __builtin_amdgcn_make_buffer_rsrc((void*)A.prog, 0, prog_bytes, 0x00020000);
+    const unsigned my_prog = lane == 0 ? (unsigned)(q * A.nb + b) * kProgStride * 4u : kOob;
+    Deps D;
+    D.has_own = q > 0;
+    D.has_up = b > 0;
+    D.has_dn2 = q > 1 && b + 1 < A.nb;
+    D.own = A.prog + ((size_t)(q - 1) * A.nb + b) * kProgStride;
+    D.up = A.prog + ((size_t)q * A.nb + (b - 1)) * kProgStride;
+    D.dn2 = A.prog + ((size_t)(q - 2) * A.nb + (b + 1)) * kProgStride;
+    if ((A.n_sor & 1) && q == pairs - 1)
+        f_run<R, DPP, true>(A, T, L, F, D, my_prog);
+    else
+        f_run<R, DPP, false>(A, T, L, F, D, my_prog);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -680,7 +968,7 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
     const bool dbg = A.dbg != nullptr;
     GFill<R, R - 1>::coef(T, L, c);
     Polls pl = poll(W.D);
-    if (!wait_covered(X, pl, W.D, 2 * R)) return give_up();
+    if (!wait_covered<1, 63>(X, pl, W.D, 2 * R)) return give_up();
     if (dbg) t_start = __builtin_amdgcn_s_memtime();
     {  // centre of the first cells: position 0 (zero; LDS-fed lanes: the same zero), lane 0: halo position 63
         const unsigned first = L.pd == kOob ? kOob : L.pd - L.pd_step;
@@ -723,7 +1011,7 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
     unsigned ma = 0u, mb = 0u;
     const auto iteration = [&](int i, bool first) -> bool {
         const unsigned long long tc = dbg ? __builtin_amdgcn_s_memtime() : 0;
-        if (!first && !wait_covered(X, pl, W.D, (i + 2) * R)) return false;
+        if (!first && !wait_covered<1, 63>(X, pl, W.D, (i + 2) * R)) return false;
         if (dbg) t_cov += __builtin_amdgcn_s_memtime() - tc;
         const Polls pn = poll(W.D);
         const int s0 = i * R;
@@ -731,7 +1019,7 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
         GSeg<R, 0, CA, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
         if (!first) {  // marker A of the previous iteration
             asm volatile("" ::"v"(ma), "v"(S.duL), "v"(S.dvL) : "memory");
-            if (ma != 0u) return false;
+            if (uni(ma) != 0u) return false;
             if (lane == 0)
                 __hip_atomic_store(W.my_prog, (unsigned)min(ns, s0 - R + H), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
@@ -743,7 +1031,7 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
         GSeg<R, H, CB, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
         if (!first) {  // marker B of the previous iteration
             asm volatile("" ::"v"(mb), "v"(S.duL), "v"(S.dvL) : "memory");
-            if (mb != 0u) return false;
+            if (uni(mb) != 0u) return false;
             if (lane == 0)
                 __hip_atomic_store(W.my_prog, (unsigned)min(ns, s0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -946,8 +1234,8 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
     if (n_sor <= 0) return PAPOF_EINVAL;
     if (mode == PAPOF_SOR_EXACT) {
         if (!sp.skew) return PAPOF_EINVAL;
-        const SkewDims sd = skew_dims(H, W, n_sor, sp.sd.group);
-        if (sd.hp != sp.sd.hp || sd.npos != sp.sd.npos || sd.qt != sp.sd.qt || sd.nb != sp.sd.nb ||
+        const SkewDims sd = skew_dims(H, W, n_sor, sp.sd.group, sp.sd.fuse);
+        if (sd.fuse != sp.sd.fuse || sd.hp != sp.sd.hp || sd.npos != sp.sd.npos || sd.qt != sp.sd.qt || sd.nb != sp.sd.nb ||
             sd.n_sor != sp.sd.n_sor || sd.n > sp.cap_cells || sd.nd + sd.nh > sp.cap_cells_d)
             return PAPOF_EINVAL;  // sor_bind() must have chosen this layout (the operands were assembled in it)
         if ((sd.n + kLanes) * 16 >= (size_t(1) << 30) || (sd.nd + sd.nh) * 16 >= (size_t(1) << 30))
@@ -990,6 +1278,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.n_sor = n_sor;
         A.nalpha = nalpha;
         A.om1 = om1;
+        A.dbg = h->sor_dbg;
         // du = dv = 0 before the first sweep (src/OpticalFlow.cpp:452-453); also clears the ghost-lane mirrors
         PAPOF_HIP(hipMemsetAsync(sp.du, 0, (sd.nd + sd.nh) * 16, h->stream));  // both planes (+ the halo rows)
         if (sd.group > 1) {
@@ -1031,6 +1320,22 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             PAPOF_HIP(hipGetLastError());
             return PAPOF_OK;
         }
+        if (sd.fuse == 2) {  // two sweeps per wave (k_sor_fused); effective pipeline depth R - 2
+            const int pairs = (n_sor + 1) / 2;
+            A.xcd_affine = (h->sor_xcd_affine && (sd.nb <= 8 || h->sor_xcd_affine > 1)) ? 1 : 0;
+            const dim3 fgrid(A.xcd_affine ? 8 * ((sd.nb + 7) / 8) * pairs : sd.nb * pairs);
+            const int Rf = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 9 ? 12 : 8);
+            if (Rf <= 6)
+                hipLaunchKernelGGL((k_sor_fused<6, true>), fgrid, dim3(kLanes), 0, h->stream, A);
+            else if (Rf <= 8)
+                hipLaunchKernelGGL((k_sor_fused<8, true>), fgrid, dim3(kLanes), 0, h->stream, A);
+            else if (Rf <= 10)
+                hipLaunchKernelGGL((k_sor_fused<10, true>), fgrid, dim3(kLanes), 0, h->stream, A);
+            else
+                hipLaunchKernelGGL((k_sor_fused<12, true>), fgrid, dim3(kLanes), 0, h->stream, A);
+            PAPOF_HIP(hipGetLastError());
+            return PAPOF_OK;
+        }
         // measured: with at most one band per XCD the affinity is worth 3-4 % (small pyramid levels); beyond that the
         // uneven band count per XCD costs more than the L2 hits give (1920x1080: 18 bands over 8 XCDs, -5 %)
         A.xcd_affine = (h->sor_xcd_affine && (sd.nb <= 8 || h->sor_xcd_affine > 1)) ? 1 : 0;
@@ -1039,7 +1344,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         // also what a hand-off costs.  Measured (profiles/r01_s2_sor_depth_sweep.txt): the big levels want the deeper
         // pipeline (throughput; with the mid-iteration poll 1440x810: 0.85 -> 0.81 ms, 1080x607: 0.68 -> 0.65 ms), the
         // small, hand-off-bound levels the shorter one (607x341: 0.53 -> 0.47 ms).
-        const int R = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 9 ? 10 : 6);
+        const int R = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 8 ? 8 : 6);
         if (!h->use_dpp)
             hipLaunchKernelGGL((k_sor_exact<8, false>), grid, block, 0, h->stream, A);
         else if (R <= 4)
@@ -1111,9 +1416,16 @@ int sor_group_size(const papof_handle* h, int H, int W, int n_sor) {
     return g >= 2 ? 2 : 1;
 }
 
+// Sweeps per wave: the fused-pair kernel needs the verified DPP lane shifts and excludes the grouped kernel.
+static int sor_fuse_size(const papof_handle* h, int n_sor, int group) {
+    if (!h || !h->use_dpp || n_sor < 2 || group > 1) return 1;
+    return h->sor_fuse == 2 ? 2 : 1;
+}
+
 int sor_bind(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor) {
     if (!sp.skew) return PAPOF_OK;
-    const SkewDims sd = skew_dims(H, W, n_sor, sor_group_size(h, H, W, n_sor));
+    const int group = sor_group_size(h, H, W, n_sor);
+    const SkewDims sd = skew_dims(H, W, n_sor, group, sor_fuse_size(h, n_sor, group));
     if (sd.n > sp.cap_cells || sd.nd + sd.nh > sp.cap_cells_d) return PAPOF_ENOMEM;
     sp.sd = sd;
     return PAPOF_OK;
@@ -1125,9 +1437,8 @@ int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes&
     sp.cap_cells = sp.cap_cells_d = 0;
     sp.sd = SkewDims{};
     if (sp.skew) {
-        sp.sd = skew_dims(H, W, n_sor_cap, 2);  // any group size > 1: capacity includes the halo rows
-        sp.cap_cells = sp.sd.n;
-        sp.cap_cells_d = sp.sd.nd + sp.sd.nh;
+        sp.sd = skew_dims(H, W, n_sor_cap, 2);
+        skew_capacity(H, W, n_sor_cap, sp.cap_cells, sp.cap_cells_d);  // whichever layout sor_bind() chooses later
         const size_t n = 2 * (sp.cap_cells + kLanes);  // doubles per paired plane
         sp.phi = A.f64(n);
         sp.xy = sp.phi ? sp.phi + 1 : nullptr;

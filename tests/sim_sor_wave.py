@@ -21,7 +21,7 @@ thousands of cells concurrently.  Work decomposition, as in the H
   lane l+1; right-old is LOADED (it becomes the next centre);
 * every load is issued R steps before its use (software pipeline).  Before iteration i issues its loads -- which are
   for steps < (i+2)R =: e -- the task needs
-      prog[k-1][b]   >= min(NS, e + 1)     own band, previous sweep (centre / right-old / row below)
+      prog[k-1][b]   >= min(NS, e)         own band, previous sweep (centre / right-old / row below)
       prog[k][b-1]   >= min(NS, e + 63)    band above, this sweep   (ghost lane 0)
       prog[k-2][b+1] >= min(NS, e - 62)    band below, two sweeps ago: it must have read cell 62 of our block before
                                            this sweep reuses the block (write-after-read; practically never binding)
@@ -102,7 +102,7 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0, use_d
     def covered(b, k, e):
         ok = True
         if k > 0:
-            ok = ok and prog[b, k - 1] >= min(ns, e + 1)
+            ok = ok and prog[b, k - 1] >= min(ns, e)
         if b > 0:
             ok = ok and prog[b - 1, k] >= min(ns, e + 63)
         if use_dn2 and k > 1 and b + 1 < nb:
@@ -135,8 +135,9 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0, use_d
         for ti in rng.permutation(len(pending)):
             t = pending[ti]
             b, k = t.b, t.k
-            if t.i < 0:  # prologue: needs coverage of steps < 2R, then the first centre and the first R slots
-                if not covered(b, k, 2 * r):
+            if t.i < 0:  # prologue (staged start-up): coverage of steps < R, then the first centre and the first R slots;
+                # the refills of iteration 0 (steps < 2R) are checked at its start like those of every other iteration
+                if not covered(b, k, r):
                     continue
                 t.duC, t.dvC = load_pd(0, b, k, -1), load_pd(1, b, k, -1)
                 for s in range(r):
@@ -145,7 +146,7 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0, use_d
                 ran = True
                 break
             i = t.i
-            if i > 0 and not covered(b, k, (i + 2) * r):
+            if not covered(b, k, (i + 2) * r):
                 continue
             ran = True
             for s in range(i * r, (i + 1) * r):
