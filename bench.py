@@ -10,7 +10,7 @@ iterations at every level, exact (reference-order) SOR, fp64.  N>1 = replicas, o
 (weak scaling, no data-path collective; see DESIGN.md "Multi-GPU").
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- for the dominant kernel (k_sor_exact): algorithmic bytes (80 B per cell-update)
+  roofline     -- for the dominant kernel (the exact-order SOR solve: k_sor_exact, and k_sor_fused on the full-size level): algorithmic bytes (80 B per cell-update)
                   of all SOR launches of a step / their summed duration, measured live with HIP events recorded on
                   the library's own stream around every SOR launch inside the timed region;
   cpu_baseline -- the same workload run once on ONE host core by the untouched reference (oracle/_ref, kind
@@ -362,7 +362,7 @@ def main():
                        "pairs_in_flight_per_gpu": args.pairs,
                        "parallelism": "replicas: one independent frame pair per GPU" if world > 1 else "1 GPU"},
             "max_abs_duv_vs_reference": parity,
-            "roofline": {"bound": "hbm", "kernel": "k_sor_exact" if mode == 0 else "k_sor_" + args.mode,
+            "roofline": {"bound": "hbm", "kernel": "k_sor_exact + k_sor_fused (exact-order SOR solves)" if mode == 0 else "k_sor_" + args.mode,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches_per_step": launches, "cell_updates_per_step": updates,

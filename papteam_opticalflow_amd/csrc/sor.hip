@@ -921,13 +921,22 @@ struct GFill<R, -1> {
 
 // LDS progress words: the LDS unit executes a wave's operations in order, so cells written before a word are visible to
 // whoever has seen the word; an explicit lgkmcnt wait keeps the issue order.  Bounded like every other wait.
+// All control flow stays wave-uniform (see uni()): words are read through v_readfirstlane, and a word is written by
+// lane 0 WITHOUT a branch -- EXEC is narrowed to lane 0 around the ds_write inside one asm statement.
+__device__ __forceinline__ void lds_store_lane0(lds_word* p, unsigned v) {
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "v"((unsigned)(unsigned long long)(const volatile void __attribute__((address_space(3)))*)p), "v"(v)
+                 : "memory");
+}
 __device__ __forceinline__ bool lds_wait_ge(lds_word* p, unsigned need, lds_word* group_abort) {
     // LDS accesses only: a vector-memory instruction inside this loop would make the loop exit a join of different
     // vmcnt states, and the compiler would drain the operand pipeline (`s_waitcnt vmcnt(0)`) after every wait
     unsigned spins = 0;
-    while (*p < need) {
+    while (uni(*p) < need) {
         __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 255u) == 0u && (*group_abort != 0u || spins > (kSpinLimit << 3))) return false;
+        if ((++spins & 255u) == 0u && (uni(*group_abort) != 0u || spins > (kSpinLimit << 3))) return false;
     }
     asm volatile("" ::: "memory");
     return true;
@@ -938,7 +947,7 @@ struct GWaveCtx {  // wave-uniform
     lds_word *done_in, *taken_in, *done_out, *taken_out;
     lds_word* group_abort;  // set by a wave of the group that gives up, so that its siblings stop waiting for it
     int task;               // k * nb + b (diagnostics)
-    unsigned* my_prog;
+    unsigned my_prog;  // lane 0: byte offset of the task's counter, other lanes: out of range
     Deps D;
     int ns, n_iter;
 };
@@ -953,7 +962,7 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
     X.ns = ns;
     // giving up (abort seen, or a bounded wait expired): tell the siblings, and the host through the abort word
     const auto give_up = [&]() {
-        *W.group_abort = 1u;
+        lds_store_lane0(W.group_abort, 1u);
         __hip_atomic_store(A.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     State S;
@@ -996,11 +1005,11 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
     const auto half_end = [&](int sa) {
         if (FROM_LDS) {
             asm volatile("" ::: "memory");
-            if (lane == 0) *W.taken_in = (unsigned)(sa + H);  // the H blocks are in registers and consumed
+            lds_store_lane0(W.taken_in, (unsigned)(sa + H));  // the H blocks are in registers and consumed
         }
         if (TO_LDS) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) *W.done_out = (unsigned)(sa + H);
+            lds_store_lane0(W.done_out, (unsigned)(sa + H));
         }
     };
 
@@ -1020,9 +1029,7 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
         if (!first) {  // marker A of the previous iteration
             asm volatile("" ::"v"(ma), "v"(S.duL), "v"(S.dvL) : "memory");
             if (uni(ma) != 0u) return false;
-            if (lane == 0)
-                __hip_atomic_store(W.my_prog, (unsigned)min(ns, s0 - R + H), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            publish(T, W.my_prog, (unsigned)min(ns, s0 - R + H));
         }
         GSeg<R, CA, H, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
         ma = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // marker A: after step H - 1
@@ -1032,8 +1039,7 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
         if (!first) {  // marker B of the previous iteration
             asm volatile("" ::"v"(mb), "v"(S.duL), "v"(S.dvL) : "memory");
             if (uni(mb) != 0u) return false;
-            if (lane == 0)
-                __hip_atomic_store(W.my_prog, (unsigned)min(ns, s0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            publish(T, W.my_prog, (unsigned)min(ns, s0));
         }
         GSeg<R, CB, R, DPP, FROM_LDS, TO_LDS>::run(A, T, L, W.ring_out, lane, om1, s0, c, lpd, S);
         mb = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // marker B: after step R - 1
@@ -1045,8 +1051,8 @@ __device__ __forceinline__ void g_run_wave(const GroupArgs& A, const Task& T, co
     for (int i = 1; i < W.n_iter; ++i)
         if (!iteration(i, false)) return give_up();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(W.my_prog, (unsigned)ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (dbg && lane == 0) {
+    publish(T, W.my_prog, (unsigned)ns);
+    if (dbg) {  // every lane stores the same
         unsigned long long* o = A.dbg + (size_t)W.task * 4;
         o[0] = __builtin_amdgcn_s_memtime() - t_start;
         o[1] = t_cov;
@@ -1064,11 +1070,9 @@ __global__ __launch_bounds__(64 * M) void k_sor_group(GroupArgs A) {
     __shared__ unsigned lds_abort;
     const unsigned lane = threadIdx.x & 63u;
     const int m = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform by construction
-    if (lane == 0) {
-        lds_done[m] = 0u;
-        lds_taken[m] = 0u;
-        if (m == 0) lds_abort = 0u;
-    }
+    lds_store_lane0((lds_word*)&lds_done[m], 0u);
+    lds_store_lane0((lds_word*)&lds_taken[m], 0u);
+    lds_store_lane0((lds_word*)&lds_abort, 0u);  // every wave writes the same 0 before the barrier
     __syncthreads();  // the only barrier: every wave is still here
     int g, b;
     if (A.xcd_affine) {
@@ -1119,20 +1123,17 @@ __global__ __launch_bounds__(64 * M) void k_sor_group(GroupArgs A) {
     const auto halo_row = [&](int kk, int bb) {  // byte offset of HALO[kk][bb][0]
         return A.halo_off + (unsigned)((kk * A.nb + bb) * A.npos_d) * 16u;
     };
-    if (lane == 0) {  // the row above, NEW value: lane 62 of (b-1, k), 63 steps ahead of ours -> halo position s + 64
-        L.pd = b > 0 ? halo_row(k, b - 1) + 64u * 16u : kOob;
-        L.pd_step = 16u;
-    } else if (from_lds) {
-        L.pd = kOob;
-        L.pd_step = 0u;
-    } else {  // wave 0: own block of the previous group's plane, cell lane - 1
-        L.pd = prev + L.pos_d + (unsigned)b * kBlock + (lane - 1u) * 16u;
-        L.pd_step = L.pos_d;
-    }
+    // lane 0: the row above, NEW value: lane 62 of (b-1, k), 63 steps ahead of ours -> halo position s + 64;
+    // LDS-fed lanes: off; wave 0: own block of the previous group's plane, cell lane - 1   (selects, no branches)
+    const unsigned pd_halo = b > 0 ? halo_row(k, b - 1) + 64u * 16u : kOob;
+    const unsigned pd_plane = prev + L.pos_d + (unsigned)b * kBlock + (lane - 1u) * 16u;
+    L.pd = lane == 0 ? pd_halo : (from_lds ? kOob : pd_plane);
+    L.pd_step = lane == 0 ? 16u : (from_lds ? 0u : L.pos_d);
     L.hs = (lane == kLanes - 2 && b + 1 < A.nb) ? halo_row(k, b) + 16u : kOob;  // step s -> position s + 1
     const double om1 = ghost ? 1.0 : A.om1;
 
-    W.my_prog = A.prog + ((size_t)k * A.nb + b) * kProgStride;
+    T.rp = __builtin_amdgcn_make_buffer_rsrc((void*)A.prog, 0, (unsigned)A.n_sor * (unsigned)A.nb * kProgStride * 4u, 0x00020000);
+    W.my_prog = lane == 0 ? (unsigned)(k * A.nb + b) * kProgStride * 4u : kOob;
     W.D.has_own = m == 0 && k > 0;  // inside a group the previous sweep arrives through LDS
     W.D.has_up = b > 0;
     W.D.has_dn2 = false;            // planes are read by the own band only, halo rows are never reused
@@ -1324,7 +1325,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             const int pairs = (n_sor + 1) / 2;
             A.xcd_affine = (h->sor_xcd_affine && (sd.nb <= 8 || h->sor_xcd_affine > 1)) ? 1 : 0;
             const dim3 fgrid(A.xcd_affine ? 8 * ((sd.nb + 7) / 8) * pairs : sd.nb * pairs);
-            const int Rf = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 9 ? 12 : 8);
+            const int Rf = h->sor_depth > 0 ? h->sor_depth : 6;
             if (Rf <= 6)
                 hipLaunchKernelGGL((k_sor_fused<6, true>), fgrid, dim3(kLanes), 0, h->stream, A);
             else if (Rf <= 8)
@@ -1416,16 +1417,20 @@ int sor_group_size(const papof_handle* h, int H, int W, int n_sor) {
     return g >= 2 ? 2 : 1;
 }
 
-// Sweeps per wave: the fused-pair kernel needs the verified DPP lane shifts and excludes the grouped kernel.
-static int sor_fuse_size(const papof_handle* h, int n_sor, int group) {
+// Sweeps per wave: the fused-pair kernel needs the verified DPP lane shifts and excludes the grouped kernel.  Measured
+// (profiles/r01_s3_sor_sweeps.txt): its step costs 1.7x a plain step (the arithmetic of two sweeps; a wave cannot issue
+// fp64 faster), but it moves half the bytes, so it wins where the solve is bandwidth-bound -- 1920x1080: 0.98 -> 0.91 ms
+// -- and loses on the hand-off-bound levels below ~16 bands.
+static int sor_fuse_size(const papof_handle* h, int H, int W, int n_sor, int group) {
     if (!h || !h->use_dpp || n_sor < 2 || group > 1) return 1;
-    return h->sor_fuse == 2 ? 2 : 1;
+    if (h->sor_fuse > 0) return h->sor_fuse == 2 ? 2 : 1;
+    return skew_dims(H, W, n_sor).nb >= 16 ? 2 : 1;
 }
 
 int sor_bind(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor) {
     if (!sp.skew) return PAPOF_OK;
     const int group = sor_group_size(h, H, W, n_sor);
-    const SkewDims sd = skew_dims(H, W, n_sor, group, sor_fuse_size(h, n_sor, group));
+    const SkewDims sd = skew_dims(H, W, n_sor, group, sor_fuse_size(h, H, W, n_sor, group));
     if (sd.n > sp.cap_cells || sd.nd + sd.nh > sp.cap_cells_d) return PAPOF_ENOMEM;
     sp.sd = sd;
     return PAPOF_OK;

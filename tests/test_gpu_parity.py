@@ -267,18 +267,25 @@ def test_pyflow_dropin_entry_point(oracle):
 
 @pytest.mark.parametrize("knob,value", [("PAPOF_SOR_GROUP", "2"), ("PAPOF_SOR_GROUP", "4"), ("PAPOF_SOR_DEPTH", "4"),
                                         ("PAPOF_SOR_DEPTH", "8"), ("PAPOF_SOR_DEPTH", "12"), ("PAPOF_SOR_XCD", "0"),
-                                        ("PAPOF_SOR_XCD", "2"), ("PAPOF_OVERLAP", "0"), ("PAPOF_SOR_XLANE", "shfl")])
+                                        ("PAPOF_SOR_XCD", "2"), ("PAPOF_OVERLAP", "0"), ("PAPOF_SOR_XLANE", "shfl"),
+                                        ("PAPOF_SOR_FUSE", "2"), ("PAPOF_SOR_FUSE", "1"), ("PAPOF_SOR_FUSE+DEPTH", "2+10")])
 def test_every_solver_variant_matches_oracle(oracle, knob, value, monkeypatch):
     """Every tuning knob selects code that must give the reference's bits too: the opt-in grouped solver
     (PAPOF_SOR_GROUP: M sweeps of a band per workgroup, LDS hand-off; sor.hip k_sor_group), the pipeline depths the
-    size heuristic does not pick, the XCD mappings, the single-stream orchestration, the ds_bpermute lane shifts."""
+    size heuristic does not pick, the XCD mappings, the single-stream orchestration, the ds_bpermute lane shifts, and
+    the fused kernel (PAPOF_SOR_FUSE=2: two sweeps per wave, k_sor_fused; even and odd sweep counts, one and many bands)
+    forced on for every size / forced off."""
     from papteam_opticalflow_amd import Papof
     group = knob + "=" + value
-    monkeypatch.setenv(knob, value)
+    if knob == "PAPOF_SOR_FUSE+DEPTH":
+        monkeypatch.setenv("PAPOF_SOR_FUSE", value.split("+")[0])
+        monkeypatch.setenv("PAPOF_SOR_DEPTH", value.split("+")[1])
+    else:
+        monkeypatch.setenv(knob, value)
     g = Papof(0)  # the environment is read when the handle is created
     try:
         for h, w, n_sor in [(70, 50, 4), (130, 37, 3), (1, 5, 3), (129, 3, 2), (341, 607, 42), (540, 960, 30),
-                            (200, 1000, 7), (63, 64, 1), (125, 66, 9)]:
+                            (200, 1000, 7), (63, 64, 1), (125, 66, 9), (61, 40, 2), (60, 33, 5), (1100, 300, 5)]:
             planes = _sor_planes(h, w, h * 7 + w)
             du, dv = g.sor(*planes, n_sor, mode=0)
             eu, ev = oracle.sor(*planes, n_sor, mode=0)

@@ -24,7 +24,7 @@ def per_dispatch(path, counter, kernel):
 
 def main():
     fetch_csv, write_csv, key = sys.argv[1:4]
-    kernel = sys.argv[4] if len(sys.argv) > 4 else "k_sor_exact"
+    kernel = sys.argv[4] if len(sys.argv) > 4 else "k_sor_"  # k_sor_exact and k_sor_fused: every solve of the call
     f = per_dispatch(fetch_csv, "FETCH_SIZE", kernel)
     w = per_dispatch(write_csv, "WRITE_SIZE", kernel)
     out = {"kernel": kernel, "launches_sampled": [len(f), len(w)],
