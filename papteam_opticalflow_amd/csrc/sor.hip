@@ -431,7 +431,9 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     // lanes >= 1: own block, cell lane - 1; lane 0: the row above, NEW value: block b-1, cell 62, written by (b-1, k) 63
     // steps ahead of ours.  (Selects, not branches: a divergent branch anywhere makes the compiler structurise the kernel.)
     const unsigned pd_above = b > 0 ? mine + 64u * L.pos_d + (unsigned)(b - 1) * kBlock + 62u * 16u : kOob;
-    L.pd = lane == 0 ? pd_above : prev + L.pos_d + (unsigned)b * kBlock + (lane - 1u) * 16u;
+    // Sweep 0 reads du = dv = 0 (src/OpticalFlow.cpp:452-453) as out-of-range offsets, not from memory: the planes need
+    // no clearing between solves except for the tail positions no task writes (sor_solve clears them anyway: cache warming).
+    L.pd = lane == 0 ? pd_above : (k > 0 ? prev + L.pos_d + (unsigned)b * kBlock + (lane - 1u) * 16u : kOob);
     const double om1 = ghost ? 1.0 : A.om1;  // ghost lanes pass their centre value through unchanged
 
     // one 128-byte line per counter: hundreds of waves publish and poll concurrently, and counters sharing a
@@ -462,8 +464,9 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     Unroll<R, R - 1, DPP>::fill_coef(T, L, c);
     Polls pl = poll(D);
     if (!wait_covered<0, 63>(A, pl, D, R)) end_task();
-    {  // centre of the first cells = the right-old of "step -1" (position 0: zero; lane 0: position 63 above)
-        const unsigned first = L.pd == kOob ? kOob : L.pd - L.pos_d;
+    {  // centre of the first cells = the right-old of "step -1" (lanes >= 1: left of column 0, zero; lane 0: position 63
+       // of the block above)
+        const unsigned first = (lane != 0 || L.pd == kOob) ? kOob : L.pd - L.pos_d;
         const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, first, 0, kAuxSc1));
         S.duC = c0.x;
         S.dvC = c0.y;
@@ -556,6 +559,7 @@ struct FLane {       // per-lane constants of the fused kernel (VGPRs)
     double om1a;     // 1 - omega of the first sweep (1.0 on ghost lanes)
     double om1b;     // ... of the second sweep
     bool first_out;  // lane 62: stores its first-sweep result
+    bool own_block;  // lanes >= 2: the first sweep's operands come from the own block (lanes 0 / 1: from the band above)
 };
 
 template <int R, int t, bool DPP, bool SKIP2, bool ID2>
@@ -662,8 +666,8 @@ __device__ __forceinline__ void f_run(const ExactArgs& A, const Task& T, const L
     Unroll<R, R - 1, DPP>::fill_coef(T, L, c);
     Polls pl = poll(D);
     if (!wait_covered<1, 64>(A, pl, D, R)) end_task();  // staged start-up, see k_sor_exact
-    {  // centre of the first cells = the right operand of "step -1"
-        const unsigned first = L.pd == kOob ? kOob : L.pd - L.pos_d;
+    {  // centre of the first cells = the right operand of "step -1" (lanes >= 2: left of column 0, zero)
+        const unsigned first = (F.own_block || L.pd == kOob) ? kOob : L.pd - L.pos_d;
         const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, first, 0, kAuxSc1));
         S1.duC = c0.x;
         S1.dvC = c0.y;
@@ -749,7 +753,7 @@ __global__ __launch_bounds__(64) void k_sor_fused(ExactArgs A) {
     // lane 0: row above that at sweep k+1 = second-sweep result of lane 61 of (b-1, q), stored at its step s + 64
     const unsigned pd1 = b > 0 ? mine + 63u * L.pos_d + (unsigned)(b - 1) * kBlock + 62u * 16u : kOob;
     const unsigned pd0 = b > 0 ? mine + 65u * L.pos_d + (unsigned)(b - 1) * kBlock + 61u * 16u : kOob;
-    const unsigned pd_own = prev + 2u * L.pos_d + (unsigned)b * kBlock + (lane - 2u) * 16u;
+    const unsigned pd_own = q > 0 ? prev + 2u * L.pos_d + (unsigned)b * kBlock + (lane - 2u) * 16u : kOob;  // pair 0: zeros
     L.pd = lane == 0 ? pd0 : (lane == 1 ? pd1 : pd_own);
     FLane F;
     const bool real1 = lane >= 2 && lane <= kLanes - 2;
@@ -757,6 +761,7 @@ __global__ __launch_bounds__(64) void k_sor_fused(ExactArgs A) {
     F.om1a = real1 ? A.om1 : 1.0;
     F.om1b = (lane == 0 || lane == kLanes - 1) ? 1.0 : A.om1;
     F.first_out = lane == kLanes - 2;
+    F.own_block = lane >= 2;
 
     const unsigned prog_bytes = (unsigned)A.n_sor * (unsigned)A.nb * kProgStride * 4u;
     T.rp = __builtin_amdgcn_make_buffer_rsrc((void*)A.prog, 0, prog_bytes, 0x00020000);
@@ -1280,8 +1285,22 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.nalpha = nalpha;
         A.om1 = om1;
         A.dbg = h->sor_dbg;
-        // du = dv = 0 before the first sweep (src/OpticalFlow.cpp:452-453); also clears the ghost-lane mirrors
-        PAPOF_HIP(hipMemsetAsync(sp.du, 0, (sd.nd + sd.nh) * 16, h->stream));  // both planes (+ the halo rows)
+        // The (du, dv) planes.  The grouped kernel reads du = dv = 0 before the first sweep (src/OpticalFlow.cpp:452-453) and
+        // its halo rows from memory.  k_sor_exact / k_sor_fused read those zeros as out-of-range offsets and write every
+        // position 1 .. n_iter * R of a plane before anybody reads it, so all they NEED cleared are the tail positions
+        // that ghost lanes read up to 65 steps ahead and nobody writes (PAPOF_SOR_CLEAR=tail: one strided memset).  Yet
+        // clearing both planes entirely is what is done by default, because it is FASTER, its own cost included: the
+        // memset leaves the planes resident in the Infinity Cache, and every level's solve then runs 4-5 % faster
+        // (1920x1080: 0.941 -> 0.900 ms, 607x341: 0.354 -> 0.338 ms, a whole 1080p pair 11.98 -> 11.56 ms).
+        static const char* const clear_env = std::getenv("PAPOF_SOR_CLEAR");
+        static const bool clear_tail_only = clear_env && std::strcmp(clear_env, "tail") == 0;
+        if (sd.group > 1 || !clear_tail_only) {
+            PAPOF_HIP(hipMemsetAsync(sp.du, 0, (sd.nd + sd.nh) * 16, h->stream));  // both planes (+ the halo rows)
+        } else {
+            const size_t block = (size_t)sd.nb * kLanes * 16, par = (size_t)sd.npos_d * block;
+            PAPOF_HIP(hipMemset2DAsync((char*)sp.du + (size_t)sd.ns * block, par, 0, (size_t)(sd.npos_d - sd.ns) * block, 2,
+                                       h->stream));
+        }
         if (sd.group > 1) {
             GroupArgs Ga;
             Ga.phi = sp.phi;

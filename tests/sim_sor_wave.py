@@ -88,8 +88,9 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0, use_d
     lay = layout(h, w, n_sor, r)
     nb, ns, rt, qt = lay["nb"], lay["ns"], lay["rt"], lay["qt"]
     P = {n: to_skew(p, lay) for n, p in dict(phi=phi, xy=imdxy, a1=a1, a2=a2, b1=b1, b2=b2).items()}
-    npos_d = ns + 2 * r + 4
-    D = np.zeros((2, 2, npos_d, nb, LANES))  # [du|dv][parity][position][band][cell]; memset before every solve
+    npos_d = ns + 2 * r + 72
+    D = np.zeros((2, 2, npos_d, nb, LANES))  # [du|dv][parity][position][band][cell]
+    D[:, :, :ns] = np.nan  # only the tail positions must be zero (sor_solve); poison whatever a task has to write first
     prog = np.zeros((nb, n_sor), dtype=np.int64)
     nalpha = -alpha
     om1 = np.full(LANES, 1 - omega)
@@ -117,7 +118,8 @@ def simulate(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0, use_d
         """right-old of step s (-1: the first centre): lanes >= 1 <- cells lane-1 of own block, previous parity;
         lane 0 <- cell 62 of the block above, this parity, 63 positions ahead"""
         v = np.zeros(LANES)
-        v[1:] = D[c, (k - 1) & 1, s + 1, b, :63]
+        if k > 0 and s >= 0:  # sweep 0 reads du = dv = 0 as out-of-range offsets; step -1 is left of column 0
+            v[1:] = D[c, (k - 1) & 1, s + 1, b, :63]
         if b > 0 and s + 64 < npos_d:
             v[0] = D[c, k & 1, s + 64, b - 1, 62]
         return v
@@ -353,3 +355,170 @@ def simulate_grouped(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, group
     ii, jj = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
     bb, cc = (ii + kl) // ROWS, 1 + (ii + kl) % ROWS
     return D[0, gl & 1, jj + cc + 1, bb, cc], D[1, gl & 1, jj + cc + 1, bb, cc]
+
+
+FROWS = LANES - 3  # fused pairs: 61 rows per band
+
+
+def layout_fused(h, w, n_sor, r=8):
+    last = (n_sor + 1) // 2 - 1  # index of the last pair of sweeps
+    nb = (h + 2 * last + 1 + FROWS - 1) // FROWS
+    ns = w + LANES - 1
+    rt = qt = n_sor + 3
+    hp = (rt + FROWS * nb + 4 + 7) // 8 * 8
+    npos = qt + ns + 2 * r + 2 + FROWS * (nb - 1) + 2
+    return dict(nb=nb, ns=ns, rt=rt, qt=qt, hp=hp, npos=npos, last=last)
+
+
+def simulate_fused(phi, imdxy, a1, a2, b1, b2, n_sor, alpha, omega, r=8, seed=0, use_dn2=True):
+    """Model of `k_sor_fused<R>` (sor.hip): task (band b, pair q) runs sweeps k = 2q and k + 1 in ONE wavefront.
+    Lane l stands for image row 61b - 2q - 2 + l in both sweeps; at step s the first sweep updates column s - l, the
+    second sweep column s - l - 2 with operands taken from the first sweep's results of steps s - 2 (centre) and s - 1
+    (right; lane l + 1's for down) and the coefficient cells of step s - 2 (their slot is refilled two steps late).
+      first sweep:  lane 0 carrier, lane 1 ghost (row above at sweep k), lanes 2..62 real, lane 63 ghost (row below)
+      second sweep: lane 0 ghost (row above at sweep k + 1), lanes 1..61 real, lane 62 not stored, lane 63 unused
+    One store per step to D[q & 1][s + 1][b]: lanes 0..61 their second-sweep result, lane 62 its FIRST-sweep result;
+    planes alternate per pair.  First-sweep operands of step s: lanes >= 2 <- previous pair's cell l - 2 at position
+    s + 2 (pair 0: zeros); lane 1 <- cell 62 of the block above at position s + 63 (its lane 62's first-sweep result);
+    lane 0 <- cell 61 of the block above at position s + 65 (its lane 61's second-sweep result).  An odd sweep count
+    makes the last pair's second sweep the identity.  Before the loads of steps < e are issued:
+        prog[q-1][b] >= min(NS, e + 1),  prog[q][b-1] >= min(NS, e + 64),  prog[q-2][b+1] >= min(NS, e - 62).
+    Random scheduler at iteration granularity, loads taken when the kernel issues them, publications lagging."""
+    h, w = phi.shape
+    lay = layout_fused(h, w, n_sor, r)
+    nb, ns, rt, qt, last = lay["nb"], lay["ns"], lay["rt"], lay["qt"], lay["last"]
+    pairs = last + 1
+    P = {n: to_skew(p, lay) for n, p in dict(phi=phi, xy=imdxy, a1=a1, a2=a2, b1=b1, b2=b2).items()}
+    npos_d = ns + 2 * r + 72
+    D = np.zeros((2, 2, npos_d, nb, LANES))  # [du|dv][parity][position][band][cell]
+    D[:, :, :ns] = np.nan                    # only the tail positions need to be cleared (sor_solve): poison the rest
+    prog = np.zeros((nb, pairs), dtype=np.int64)
+    nalpha = -alpha
+    lane = np.arange(LANES)
+    real1 = (lane >= 2) & (lane <= 62)
+    om1a = np.where(real1, 1 - omega, 1.0)
+    om1b = np.where((lane == 0) | (lane == 63), 1.0, 1 - omega)
+    coef_on = (lane != 0) & (lane != 63)     # lanes 0 / 63: (a, b) out of range -> 0
+    n_iter = (ns + r - 1) // r
+    rng = np.random.default_rng(seed)
+
+    def covered(b, q, e):
+        ok = True
+        if q > 0:
+            ok = ok and prog[b, q - 1] >= min(ns, e + 1)
+        if b > 0:
+            ok = ok and prog[b - 1, q] >= min(ns, e + 64)
+        if use_dn2 and q > 1 and b + 1 < nb:
+            ok = ok and prog[b + 1, q - 2] >= min(ns, max(0, e - 62))
+        return ok
+
+    def window(b, q):
+        r0 = FROWS * b - 2 * q - 2  # image row of lane 0
+        return r0 + qt, slice(r0 + rt, r0 + rt + LANES)
+
+    def load_pd(c, b, q, s):
+        """first-sweep right operand of step s (-1: the first centre; lanes >= 2 are then left of column 0: zero)"""
+        v = np.zeros(LANES)
+        if q > 0 and s >= 0:
+            v[2:] = D[c, (q - 1) & 1, s + 2, b, :62]
+        if b > 0:
+            if s + 63 < npos_d:
+                v[1] = D[c, q & 1, s + 63, b - 1, 62]
+            if s + 65 < npos_d:
+                v[0] = D[c, q & 1, s + 65, b - 1, 61]
+        return v
+
+    def load_coef(b, q, s):
+        q0, rows = window(b, q)
+        g = lambda n: P[n][q0 + s, rows].copy()
+        z = lambda n: np.where(coef_on, P[n][q0 + s, rows], 0.0)
+        return dict(phi=g("phi"), xy=g("xy"), a1=z("a1"), a2=z("a2"), b1=z("b1"), b2=z("b2"))
+
+    class FTask:
+        def __init__(self, b, q):
+            self.b, self.q, self.i = b, q, -1
+            z = np.zeros(LANES)
+            self.s1 = dict(duL=z.copy(), dvL=z.copy(), phiL=z.copy(), duC=z.copy(), dvC=z.copy())
+            self.s2 = dict(duL=z.copy(), dvL=z.copy(), phiL=z.copy(), duC=z.copy(), dvC=z.copy())
+            self.coef = [None] * r
+            self.pd = [None] * r
+
+    def update(st, phiC, xy, a1_, a2_, b1_, b2_, duR, dvR, om1):
+        duU, dvU, phiU = shift_up(st["duL"]), shift_up(st["dvL"]), shift_up(st["phiL"])
+        duD, dvD = shift_down(duR), shift_down(dvR)
+        s1 = st["phiL"] * st["duL"]
+        s2 = st["phiL"] * st["dvL"]
+        s1 = s1 + phiC * duR
+        s2 = s2 + phiC * dvR
+        s1 = s1 + phiU * duU
+        s2 = s2 + phiU * dvU
+        s1 = s1 + phiC * duD
+        s2 = s2 + phiC * dvD
+        s1 = s1 * nalpha
+        s2 = s2 * nalpha
+        s1 = s1 + xy * st["dvC"]
+        duN = om1 * st["duC"] + a1_ * (b1_ - s1)
+        s2 = s2 + xy * duN
+        dvN = om1 * st["dvC"] + a2_ * (b2_ - s2)
+        return duN, dvN
+
+    pending = [FTask(b, q) for q in range(pairs) for b in range(nb)]
+    while pending:
+        ran = False
+        for ti in rng.permutation(len(pending)):
+            t = pending[ti]
+            b, q = t.b, t.q
+            identity2 = (n_sor & 1) == 1 and q == pairs - 1
+            if t.i < 0:  # staged start-up: coefficients of the first R steps at once, unknowns once steps < R are covered
+                if not covered(b, q, r):
+                    continue
+                t.s1["duC"], t.s1["dvC"] = load_pd(0, b, q, -1), load_pd(1, b, q, -1)
+                for s in range(r):
+                    t.coef[s] = load_coef(b, q, s)
+                    t.pd[s] = (load_pd(0, b, q, s), load_pd(1, b, q, s))
+                t.i = 0
+                ran = True
+                break
+            i = t.i
+            if not covered(b, q, (i + 2) * r):
+                continue
+            ran = True
+            with np.errstate(invalid="ignore"):
+                for s in range(i * r, (i + 1) * r):
+                    c1 = t.coef[s % r]
+                    duR, dvR = t.pd[s % r]
+                    duR2, dvR2 = t.s1["duL"], t.s1["dvL"]  # first-sweep results of step s - 1
+                    if s < 2:
+                        duN2 = np.zeros(LANES)
+                        dvN2 = np.zeros(LANES)
+                    elif identity2:
+                        duN2, dvN2 = t.s2["duC"], t.s2["dvC"]
+                    else:
+                        c2 = t.coef[(s - 2) % r]
+                        duN2, dvN2 = update(t.s2, c2["phi"], c2["xy"], c2["a1"], c2["a2"], c2["b1"], c2["b2"], duR2, dvR2,
+                                            om1b)
+                        t.s2["phiL"] = c2["phi"]
+                    a1m, a2m = np.where(real1, c1["a1"], 0.0), np.where(real1, c1["a2"], 0.0)
+                    duN, dvN = update(t.s1, c1["phi"], c1["xy"], a1m, a2m, c1["b1"], c1["b2"], duR, dvR, om1a)
+                    out_u = np.where(lane == 62, duN, duN2)
+                    out_v = np.where(lane == 62, dvN, dvN2)
+                    D[0, q & 1, s + 1, b, :63] = out_u[:63]  # lane 63 does not store
+                    D[1, q & 1, s + 1, b, :63] = out_v[:63]
+                    t.s2["duL"], t.s2["dvL"], t.s2["duC"], t.s2["dvC"] = duN2, dvN2, duR2, dvR2
+                    t.s1["duL"], t.s1["dvL"], t.s1["phiL"] = duN, dvN, c1["phi"]
+                    t.s1["duC"], t.s1["dvC"] = duR, dvR
+                    t.pd[s % r] = (load_pd(0, b, q, s + r), load_pd(1, b, q, s + r))  # refilled at once
+                    if s >= 2:
+                        t.coef[(s - 2) % r] = load_coef(b, q, s - 2 + r)              # refilled two steps late
+            prog[b, q] = min(ns, i * r + r // 2)
+            t.i += 1
+            if t.i == n_iter:
+                prog[b, q] = ns
+                pending.pop(ti)
+            break
+        assert ran, "deadlock in the task graph"
+    # read-out: t = i + 2*last + 1, band t // 61, cell 1 + t % 61, position j + cell + 3, plane last & 1
+    ii, jj = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    tt = ii + 2 * last + 1
+    bb, cc = tt // FROWS, 1 + tt % FROWS
+    return D[0, last & 1, jj + cc + 3, bb, cc], D[1, last & 1, jj + cc + 3, bb, cc]

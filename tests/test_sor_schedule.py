@@ -45,6 +45,20 @@ def test_grouped_wave_schedule_is_bit_exact(oracle, h, w, n_sor, chunk, group, r
     assert np.array_equal(dv, ev)
 
 
+@pytest.mark.parametrize("h,w,n_sor,chunk", [(70, 50, 4, 8), (130, 37, 3, 8), (61, 20, 2, 6), (1, 5, 3, 6), (5, 1, 5, 8),
+                                              (129, 3, 2, 6), (42, 75, 7, 10), (190, 40, 6, 8), (60, 9, 1, 6)])
+def test_fused_wave_schedule_is_bit_exact(oracle, h, w, n_sor, chunk):
+    """Two sweeps of a band per wavefront (k_sor_fused): registers hand the first sweep's results to the second; planes
+    whose non-tail positions start out as NaN prove that nothing is read before it is written."""
+    alpha, omega = 0.012, 1.8
+    phi, imdxy, imdx2, imdy2, r1, r2 = _planes(h, w, h * 1000 + w + 2)
+    a1, a2 = sim.sor_coefficients(phi, imdx2, imdy2, alpha, omega)
+    du, dv = sim.simulate_fused(phi, imdxy, a1, a2, r1, r2, n_sor, alpha, omega, r=chunk, seed=h + w)
+    eu, ev = oracle.sor(phi, imdxy, imdx2, imdy2, r1, r2, n_sor, alpha=alpha, omega=omega, mode=0)
+    assert np.array_equal(du, eu)
+    assert np.array_equal(dv, ev)
+
+
 def test_skew_roundtrip():
     rng = np.random.default_rng(0)
     p = rng.standard_normal((150, 33))
