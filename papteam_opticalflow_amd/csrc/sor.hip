@@ -1285,6 +1285,10 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.nalpha = nalpha;
         A.om1 = om1;
         A.dbg = h->sor_dbg;
+        // Fault injection for the tests (tests/test_gpu_parity.py): raise the abort word before the launch, as a task whose
+        // bounded wait expired would -- every task must then END (s_endpgm on the fast path, the polling loops' abort
+        // check elsewhere) and the call must report PAPOF_ETIMEOUT instead of hanging or returning numbers.
+        if (std::getenv("PAPOF_SOR_INJECT_ABORT")) PAPOF_HIP(hipMemsetAsync(h->sync_words, 1, sizeof(unsigned), h->stream));
         // The (du, dv) planes.  The grouped kernel reads du = dv = 0 before the first sweep (src/OpticalFlow.cpp:452-453) and
         // its halo rows from memory.  k_sor_exact / k_sor_fused read those zeros as out-of-range offsets and write every
         // position 1 .. n_iter * R of a plane before anybody reads it, so all they NEED cleared are the tail positions

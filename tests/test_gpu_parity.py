@@ -299,6 +299,29 @@ def test_every_solver_variant_matches_oracle(oracle, knob, value, monkeypatch):
         g.close()
 
 
+@pytest.mark.parametrize("knob,value", [("PAPOF_SOR_FUSE", "1"), ("PAPOF_SOR_FUSE", "2"), ("PAPOF_SOR_GROUP", "4")])
+def test_raised_abort_word_ends_every_task_and_reports_timeout(oracle, knob, value, monkeypatch):
+    """The device-side waits of the exact-order kernels are bounded: a task that gives up raises an abort word, every other
+    task ends when it sees it, and the call returns PAPOF_ETIMEOUT (-5).  Injected here by raising the word before the
+    launch (PAPOF_SOR_INJECT_ABORT); afterwards the same handle must solve correctly again."""
+    from papteam_opticalflow_amd import Papof
+    from papteam_opticalflow_amd.capi import PapofError
+    monkeypatch.setenv(knob, value)
+    g = Papof(0)
+    try:
+        planes = _sor_planes(200, 300, 7)
+        want = oracle.sor(*planes, 6, mode=0)
+        monkeypatch.setenv("PAPOF_SOR_INJECT_ABORT", "1")
+        with pytest.raises(PapofError) as err:
+            g.sor(*planes, 6, mode=0)
+        assert err.value.code == -5
+        monkeypatch.delenv("PAPOF_SOR_INJECT_ABORT")
+        got = g.sor(*planes, 6, mode=0)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    finally:
+        g.close()
+
+
 def test_flow16_file_roundtrip_and_reference_layout(gpu, oracle, tmp_path):
     """save_flow16 / load_flow16: the reference's SaveOpticalFlow file layout (src/Image.h:825-837) around the GPU
     quantisation; the payload must be the oracle's bytes, and reading back gives the dequantised flow."""
