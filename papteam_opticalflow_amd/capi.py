@@ -63,7 +63,7 @@ def load():
     # of 4 hardware queues, or streams share queues and serialise: 24 pairs of 1080p, 4 in flight, 153 -> 210 Mpix/s.
     # Only effective if the runtime has not been initialised yet in this process; an explicit setting wins.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(os.environ.get("PAPOF_LIB") or LIB_PATH)  # PAPOF_LIB: another build of the same ABI (A/B measurements)
     L.papof_strerror.restype = ctypes.c_char_p
     L.papof_strerror.argtypes = [c_int]
     L.papof_last_error.restype = ctypes.c_char_p

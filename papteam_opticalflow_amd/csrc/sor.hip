@@ -66,6 +66,22 @@ namespace papof {
 
 namespace {
 
+// Tuning constants of the hand-off protocol, overridable at compile time for A/B builds (tools/ab + PAPOF_LIB; measured on
+// one box, profiles/r01_s3_ab_variants.txt): steps after which a marker is consumed at pipeline depth 6 / 8 (4 / 5: the
+// hand-off-bound levels gain 2-3 % over 3 / 5 and 4 / 4), the same for the fused kernel (3; 4 costs level 0 4 %), and
+// the depth from which the progress poll is issued in mid-iteration (8; at depth 6 it costs 12 %).
+#ifndef PAPOF_V_DM6
+#define PAPOF_V_DM6 4
+#endif
+#ifndef PAPOF_V_DM8
+#define PAPOF_V_DM8 5
+#endif
+#ifndef PAPOF_V_FDM6
+#define PAPOF_V_FDM6 3
+#endif
+#ifndef PAPOF_V_MIDPOLL
+#define PAPOF_V_MIDPOLL 8
+#endif
 constexpr int kProgStride = 32;  // unsigneds between progress counters = one 128-byte cache line each
 constexpr unsigned kSpinLimit = 4u << 20;  // bounded wait: ~4M polls (seconds), then abort
 
@@ -357,13 +373,15 @@ __device__ __forceinline__ bool covered(const Polls& p, int ns, int s_end) {
 // again be merged into the loop's latch block by the compiler (same phantom paths as above).
 __device__ __forceinline__ void end_task() { __builtin_amdgcn_endpgm(); }
 
-template <int OWN, int UP>
+template <int OWN, int UP, bool SELECTIVE = false>
 __device__ __forceinline__ bool wait_covered(const ExactArgs& A, const Polls& pl, const Deps& d, int s_end) {
     Polls p = uni(pl);
     if (!covered<OWN, UP>(p, A.ns, s_end)) {
         unsigned spins = 0;
         do {
+#ifndef PAPOF_V_NOSLEEP
             __builtin_amdgcn_s_sleep(1);
+#endif
             if ((++spins & 255u) == 0u) {
                 if (uni(__hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) return false;
                 if (spins > kSpinLimit) {
@@ -371,7 +389,17 @@ __device__ __forceinline__ bool wait_covered(const ExactArgs& A, const Polls& pl
                     return false;
                 }
             }
-            p = uni(poll(d));
+            if (!SELECTIVE) {
+                p = uni(poll(d));
+                continue;
+            }
+            // k_sor_exact polls only what is still missing (usually one counter): a shorter round, the hand-off-bound
+            // levels gain 1 %; the bandwidth-bound fused level-0 solve LOSES 4 % with it (A/B on one box), hence the flag
+            const unsigned need_own = (unsigned)min(A.ns, s_end + OWN), need_up = (unsigned)min(A.ns, s_end + UP);
+            const unsigned need_dn2 = (unsigned)min(A.ns, max(0, s_end - 62));
+            if (p.own < need_own) p.own = uni(__hip_atomic_load(d.own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (p.up < need_up) p.up = uni(__hip_atomic_load(d.up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (p.dn2 < need_dn2) p.dn2 = uni(__hip_atomic_load(d.dn2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         } while (!covered<OWN, UP>(p, A.ns, s_end));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler-only: keep the loads below the polls
@@ -463,7 +491,7 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     // first loads are in flight -- a hand-off then costs R steps and one load latency less than waiting for 2R up front.
     Unroll<R, R - 1, DPP>::fill_coef(T, L, c);
     Polls pl = poll(D);
-    if (!wait_covered<0, 63>(A, pl, D, R)) end_task();
+    if (!wait_covered<0, 63, true>(A, pl, D, R)) end_task();
     {  // centre of the first cells = the right-old of "step -1" (lanes >= 1: left of column 0, zero; lane 0: position 63
        // of the block above)
         const unsigned first = (lane != 0 || L.pd == kOob) ? kOob : L.pd - L.pos_d;
@@ -478,21 +506,21 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     // MARKER loads: a 4-byte load issued right after the store of some step retires (vmcnt is in order) only after
     // that store has completed, so consuming it a few steps later proves the step complete and lets the task
     // publish it without draining the pipeline.  Two markers per iteration (after steps H-1 and R-1), each consumed
-    // DM = R - 3 steps later, in the next iteration: published progress lags the real one by R-3 .. R-3+R/2 steps.  The
-    // marker reads the abort word, so a raised abort also ends every running task within two iterations.
-    constexpr int H = R / 2, DM = R >= 6 ? R - 3 : H;
+    // DM steps later (4 / 5 / R - 3 at depth 6 / 8 / >= 10, see PAPOF_V_DM*), in the next iteration: published progress lags
+    // the real one by DM .. DM + R/2 steps.  The marker reads the abort word, so a raised abort also ends every running task within two iterations.
+    constexpr int H = R / 2, DM = R >= 10 ? R - 3 : (R == 8 ? PAPOF_V_DM8 : (R == 6 ? PAPOF_V_DM6 : H));
     constexpr int CA = H + DM - R, CB = DM;  // steps of the NEXT iteration after which markers A / B are consumed
     static_assert(CA >= 0 && CA < H && CB >= H && CB < R, "marker consumption points");
     unsigned ma = 0u, mb = 0u;
     // one iteration = R steps; `i` is only used for step numbers.  The first iteration is peeled off the loop so that the
     // loop header joins two states with the same pipeline contents (after an iteration / after an iteration).
     const auto iteration = [&](int i, bool first) {
-        if (!wait_covered<0, 63>(A, pl, D, (i + 2) * R)) end_task();
+        if (!wait_covered<0, 63, true>(A, pl, D, (i + 2) * R)) end_task();
         // The poll for the next iteration's check is consumed at the start of the next iteration, where it waits (in
         // order) for every load issued before it.  Issued in the middle of this iteration it is half an iteration fresher
-        // (a shorter hand-off) but then waits for the refills of the first half: at R = 10 those are 5 steps old and long
-        // there (level 0: 1.10 -> 1.08 ms), at R = 6 only 3 steps (0.47 -> 0.58 ms).  Hence by depth.
-        constexpr bool kMidPoll = R >= 10;
+        // (a shorter hand-off) but then waits for the refills of the first half: at R >= 8 those are >= 4 steps old and long
+        // there (1080x607: 0.519 -> 0.505 ms, 810x455: 0.380 -> 0.370), at R = 6 only 3 steps (607x341: 0.336 -> 0.378).
+        constexpr bool kMidPoll = R >= PAPOF_V_MIDPOLL;
         Polls pn{0u, 0u, 0u};
         if (!kMidPoll) pn = poll(D);
         // Markers are consumed DM = R - 3 steps after they were issued -- i.e. in the NEXT iteration: consuming a marker
@@ -675,7 +703,7 @@ __device__ __forceinline__ void f_run(const ExactArgs& A, const Task& T, const L
     Unroll<R, R - 1, DPP>::fill_unknowns(T, L, c);
     pl = poll(D);
     // markers, polls and the peeled first iteration: exactly as in k_sor_exact (see there)
-    constexpr int H = R / 2, DM = R >= 6 ? R - 3 : H;
+    constexpr int H = R / 2, DM = R == 6 ? PAPOF_V_FDM6 : (R >= 6 ? R - 3 : H);
     constexpr int CA = H + DM - R, CB = DM;
     static_assert(CA >= 0 && CA < H && CB >= H && CB < R, "marker consumption points");
     unsigned ma = 0u, mb = 0u;
