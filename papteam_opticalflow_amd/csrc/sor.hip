@@ -82,6 +82,9 @@ namespace {
 #ifndef PAPOF_V_MIDPOLL
 #define PAPOF_V_MIDPOLL 8
 #endif
+#ifndef PAPOF_V_SLEEP
+#define PAPOF_V_SLEEP 1  // s_sleep argument (64 clocks each) between two polls of a waiting task
+#endif
 constexpr int kProgStride = 32;  // unsigneds between progress counters = one 128-byte cache line each
 constexpr unsigned kSpinLimit = 4u << 20;  // bounded wait: ~4M polls (seconds), then abort
 
@@ -379,9 +382,7 @@ __device__ __forceinline__ bool wait_covered(const ExactArgs& A, const Polls& pl
     if (!covered<OWN, UP>(p, A.ns, s_end)) {
         unsigned spins = 0;
         do {
-#ifndef PAPOF_V_NOSLEEP
-            __builtin_amdgcn_s_sleep(1);
-#endif
+            __builtin_amdgcn_s_sleep(PAPOF_V_SLEEP);
             if ((++spins & 255u) == 0u) {
                 if (uni(__hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) return false;
                 if (spins > kSpinLimit) {
