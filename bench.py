@@ -12,7 +12,8 @@ iterations at every level, exact (reference-order) SOR, fp64.  N>1 = replicas, o
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     -- for the dominant kernel (the exact-order SOR solve: k_sor_exact, and k_sor_fused on the full-size level): algorithmic bytes (80 B per cell-update)
                   of all SOR launches of a step / their summed duration, measured live with HIP events recorded on
-                  the library's own stream around every SOR launch inside the timed region;
+                  the library's own stream right around every solver kernel (behind the memsets that prepare a solve)
+                  inside the timed region;
   cpu_baseline -- the same workload run once on ONE host core by the untouched reference (oracle/_ref, kind
                   "reference") when its prebuilt .so travelled with the snapshot, else by our CPU restatement
                   (oracle/, kind "port").  Checker code, used here only as the timed CPU baseline.

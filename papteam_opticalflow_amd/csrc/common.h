@@ -242,6 +242,10 @@ struct papof_handle {
     bool use_dpp = false;            // wave_shr/wave_shl DPP moves verified on this device (else ds_bpermute)
     int sor_depth = 0;               // software-pipeline depth R (steps) of the exact-order SOR kernel; 0 = by level size
     unsigned long long* sor_dbg = nullptr;  // device buffer for per-task wait statistics (PAPOF_SOR_DBG)
+    // measurement hook: sor_solve() calls it with 1 right before and 0 right after its solver kernel(s), i.e. behind the
+    // memset nodes that prepare a solve -- so that the HIP-event time of the roofline is the kernel's own (flow_device)
+    void (*sor_mark)(void*, int) = nullptr;
+    void* sor_mark_ctx = nullptr;
     int sor_fuse = 0;                // sweeps per wave of the exact-order solver: 1 or 2; 0 = by problem size
     int sor_group = 0;               // consecutive sweeps of a band per workgroup: 1, 2 or 4; 0 = by problem size
     // second stream for everything that does not depend on the flow (pyramids, features, smoothed frame 1 of every

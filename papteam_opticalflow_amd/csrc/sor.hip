@@ -1267,6 +1267,9 @@ int sor_redblack_halfsweep(papof_handle* h, const SorPlanes& sp, int H, int W, d
 int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor, int mode) {
     const double nalpha = -alpha, om1 = 1 - omega;
     if (n_sor <= 0) return PAPOF_EINVAL;
+    const auto mark = [&](int on) {
+        if (h->sor_mark) h->sor_mark(h->sor_mark_ctx, on);
+    };
     if (mode == PAPOF_SOR_EXACT) {
         if (!sp.skew) return PAPOF_EINVAL;
         const SkewDims sd = skew_dims(H, W, n_sor, sp.sd.group, sp.sd.fuse);
@@ -1334,6 +1337,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             PAPOF_HIP(hipMemset2DAsync((char*)sp.du + (size_t)sd.ns * block, par, 0, (size_t)(sd.npos_d - sd.ns) * block, 2,
                                        h->stream));
         }
+        mark(1);  // everything below is solver kernels
         if (sd.group > 1) {
             GroupArgs Ga;
             Ga.phi = sp.phi;
@@ -1371,6 +1375,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             else
                 return PAPOF_EINVAL;
             PAPOF_HIP(hipGetLastError());
+            mark(0);
             return PAPOF_OK;
         }
         if (sd.fuse == 2) {  // two sweeps per wave (k_sor_fused); effective pipeline depth R - 2
@@ -1387,6 +1392,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             else
                 hipLaunchKernelGGL((k_sor_fused<12, true>), fgrid, dim3(kLanes), 0, h->stream, A);
             PAPOF_HIP(hipGetLastError());
+            mark(0);
             return PAPOF_OK;
         }
         // measured: with at most one band per XCD the affinity is worth 3-4 % (small pyramid levels); beyond that the
@@ -1411,16 +1417,19 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         else
             hipLaunchKernelGGL((k_sor_exact<12, true>), grid, block, 0, h->stream, A);
         PAPOF_HIP(hipGetLastError());
+        mark(0);
         return PAPOF_OK;
     }
     if (sp.skew) return PAPOF_EINVAL;
     const size_t np = (size_t)H * W;
     PAPOF_HIP(hipMemsetAsync(sp.du, 0, np * sizeof(double), h->stream));  // src/OpticalFlow.cpp:452-453
     PAPOF_HIP(hipMemsetAsync(sp.dv, 0, np * sizeof(double), h->stream));
+    mark(1);
     if (mode == PAPOF_SOR_REDBLACK) {
         for (int k = 0; k < n_sor; k++)
             for (int colour = 0; colour < 2; colour++)
                 PAPOF_TRY(sor_redblack_halfsweep(h, sp, H, W, alpha, omega, colour, Rect{0, 0, W, H}));
+        mark(0);
         return PAPOF_OK;
     }
     if (mode == PAPOF_SOR_JACOBI) {
@@ -1442,6 +1451,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             PAPOF_HIP(hipMemcpyAsync(sp.du, ru, np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
             PAPOF_HIP(hipMemcpyAsync(sp.dv, rv, np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         }
+        mark(0);
         return PAPOF_OK;
     }
     return PAPOF_EINVAL;
