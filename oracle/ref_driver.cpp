@@ -89,7 +89,8 @@ int ref_coarse2fine_flow(const double* im1, const double* im2, int h, int w, int
 // Same level loop as src/OpticalFlow.cpp:784-842 but with the iteration schedule as arguments
 // (n_outer + k*outer_step, n_sor + k*sor_step at level k), composed from the reference's own
 // public statics.  With (7,1,1,30,3) it must reproduce ref_coarse2fine_flow bit for bit
-// (checked by tests/golden/make_golden.py); config-4's "3 outer / 30 SOR" is (3,0,1,30,0).
+// (asserted by tests/test_oracle_golden.py::test_recomposed_level_loop_equals_the_reference_entry_point,
+// levels 1, 3, 5); config-4's "3 outer / 30 SOR" is (3,0,1,30,0).
 int ref_coarse2fine_flow_sched(const double* im1, const double* im2, int h, int w, int c, int levels,
                                double alpha, double ratio, int n_outer, int outer_step, int n_inner,
                                int n_sor, int sor_step, double* vx, double* vy, double* warpI2) {

@@ -248,6 +248,7 @@ struct papof_handle {
     void* sor_mark_ctx = nullptr;
     int sor_fuse = 0;                // sweeps per wave of the exact-order solver: 1 or 2; 0 = by problem size
     int sor_group = 0;               // consecutive sweeps of a band per workgroup: 1, 2 or 4; 0 = by problem size
+    int sor_resident = 0;            // tasks per launch of the exact-order kernels; 0 = 8 per CU (sor.hip: resident_tasks)
     // second stream for everything that does not depend on the flow (pyramids, features, smoothed frame 1 of every
     // level, derivative planes of the final bicubic warp): runs beside the coarse levels' latency-bound solves
     hipStream_t prep_stream = nullptr;

@@ -95,6 +95,8 @@ struct ExactArgs {
     unsigned* abort;  // one word
     int H, W, nb, ns, hp, npos, qt, rt, npos_d, n_sor;
     int xcd_affine;
+    int k0;  // first sweep (k_sor_exact) / pair (k_sor_fused) of THIS launch: a solve whose tasks exceed what the chip
+             // keeps resident is issued as consecutive launches over ranges of sweeps (sor_solve)
     double nalpha, om1;
     unsigned long long* dbg;  // diagnostics (PAPOF_SOR_DBG): per task 8 time stamps (s_memrealtime, 100 MHz), else null
 };
@@ -421,8 +423,9 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
         // XCD b % 8 in every sweep); the nb % 8 remaining bands occupy consecutive places of one more group of 8 whose
         // start moves with the sweep, so that they load every XCD equally instead of always the same ones
         const int nf = A.nb >> 3, rem = A.nb & 7, S = 8 * nf + (rem ? 8 : 0);
-        k = blockIdx.x / S;
-        const int r = blockIdx.x - k * S;
+        const int kl = blockIdx.x / S;
+        k = A.k0 + kl;
+        const int r = blockIdx.x - kl * S;
         if (r < 8 * nf) {
             b = r;
         } else {
@@ -431,8 +434,9 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
             b = 8 * nf + j;
         }
     } else {
-        k = blockIdx.x / A.nb;
-        b = blockIdx.x - k * A.nb;
+        const int kl = blockIdx.x / A.nb;
+        k = A.k0 + kl;
+        b = blockIdx.x - kl * A.nb;
     }
     const int ns = A.ns;
     const bool ghost = lane == 0 || lane == kLanes - 1;
@@ -747,8 +751,9 @@ __global__ __launch_bounds__(64) void k_sor_fused(ExactArgs A) {
     int q, b;
     if (A.xcd_affine) {  // as k_sor_exact: all pairs of a band on one XCD (<= 8 bands)
         const int nf = A.nb >> 3, rem = A.nb & 7, S = 8 * nf + (rem ? 8 : 0);
-        q = blockIdx.x / S;
-        const int r = blockIdx.x - q * S;
+        const int ql = blockIdx.x / S;
+        q = A.k0 + ql;
+        const int r = blockIdx.x - ql * S;
         if (r < 8 * nf) {
             b = r;
         } else {
@@ -757,8 +762,9 @@ __global__ __launch_bounds__(64) void k_sor_fused(ExactArgs A) {
             b = 8 * nf + j;
         }
     } else {
-        q = blockIdx.x / A.nb;
-        b = blockIdx.x - q * A.nb;
+        const int ql = blockIdx.x / A.nb;
+        q = A.k0 + ql;
+        b = blockIdx.x - ql * A.nb;
     }
     Task T;
     const unsigned plane_bytes = (unsigned)(((size_t)A.npos * A.hp + kLanes) * 16u);
@@ -835,6 +841,7 @@ struct GroupArgs {
     unsigned* abort;  // one word
     int nb, ns, hp, npos, qt, rt, npos_d, n_sor;
     int xcd_affine;
+    int g0;  // first group of sweeps of THIS launch (see ExactArgs::k0)
     unsigned long long* dbg;  // diagnostics (PAPOF_SOR_DBG): per task {total, wait_covered, lds in, lds out} shader clocks
     unsigned halo_off;  // byte offset of the halo rows from du
     double nalpha, om1;
@@ -1111,12 +1118,14 @@ __global__ __launch_bounds__(64 * M) void k_sor_group(GroupArgs A) {
     int g, b;
     if (A.xcd_affine) {
         const int x = blockIdx.x & 7, y = blockIdx.x >> 3, nb8 = (A.nb + 7) >> 3;
-        g = y / nb8;
-        b = (y - g * nb8) * 8 + x;
+        const int gl = y / nb8;
+        g = A.g0 + gl;
+        b = (y - gl * nb8) * 8 + x;
         if (b >= A.nb) return;
     } else {
-        g = blockIdx.x / A.nb;
-        b = blockIdx.x - g * A.nb;
+        const int gl = blockIdx.x / A.nb;
+        g = A.g0 + gl;
+        b = blockIdx.x - gl * A.nb;
     }
     const int k = g * M + m;
     if (k >= A.n_sor) return;
@@ -1264,6 +1273,18 @@ int sor_redblack_halfsweep(papof_handle* h, const SorPlanes& sp, int H, int W, d
     return PAPOF_OK;
 }
 
+// Tasks (waves) of the exact-order kernels that one launch may hold.  A task spins on progress counters written by tasks
+// of lower block index, which is deadlock-free only while every task of the launch is resident or the hardware
+// dispatches blocks in index order -- observed behaviour, not a HIP guarantee.  So a launch never exceeds what the chip
+// keeps resident: 8 one-wave workgroups per CU (the kernels need 140-162 VGPRs = 3 waves per SIMD = 12 per CU, the
+// margin is for whatever else runs beside the solve); larger solves become consecutive launches over ranges of sweeps --
+// the ping-pong planes and the counters carry the state across the launch boundary.  PAPOF_SOR_RESIDENT (read when the
+// handle is created) overrides the bound: the tests use it to force many launches per solve.
+static int resident_tasks(const papof_handle* h) {
+    if (h->sor_resident > 0) return h->sor_resident;
+    return std::max(64, (h->cu_count > 0 ? h->cu_count : 256) * 8);
+}
+
 int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor, int mode) {
     const double nalpha = -alpha, om1 = 1 - omega;
     if (n_sor <= 0) return PAPOF_EINVAL;
@@ -1316,6 +1337,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.n_sor = n_sor;
         A.nalpha = nalpha;
         A.om1 = om1;
+        A.k0 = 0;
         A.dbg = h->sor_dbg;
         // Fault injection for the tests (tests/test_gpu_parity.py): raise the abort word before the launch, as a task whose
         // bounded wait expired would -- every task must then END (s_endpgm on the fast path, the polling loops' abort
@@ -1358,22 +1380,28 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             Ga.dbg = h->sor_dbg;
             Ga.nalpha = nalpha;
             Ga.om1 = om1;
+            Ga.g0 = 0;
             const int groups = (n_sor + sd.group - 1) / sd.group;
             Ga.xcd_affine = (h->sor_xcd_affine && sd.nb <= 8) ? 1 : 0;
-            const dim3 ggrid(Ga.xcd_affine ? 8 * ((sd.nb + 7) / 8) * groups : sd.nb * groups);
+            const int per_g = Ga.xcd_affine ? 8 * ((sd.nb + 7) / 8) : sd.nb;  // workgroups per group of sweeps
             const int Rg = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 9 ? 10 : 8);
-            if (sd.group == 4 && Rg >= 12)
-                hipLaunchKernelGGL((k_sor_group<12, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
-            else if (sd.group == 4 && Rg >= 10)
-                hipLaunchKernelGGL((k_sor_group<10, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
-            else if (sd.group == 4 && Rg >= 8)
-                hipLaunchKernelGGL((k_sor_group<8, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
-            else if (sd.group == 4)
-                hipLaunchKernelGGL((k_sor_group<6, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
-            else if (sd.group == 2)
-                hipLaunchKernelGGL((k_sor_group<8, 2, true>), ggrid, dim3(kLanes * 2), 0, h->stream, Ga);
-            else
-                return PAPOF_EINVAL;
+            const int chunk = std::max(1, resident_tasks(h) / (per_g * sd.group));
+            for (int g0 = 0; g0 < groups; g0 += chunk) {
+                Ga.g0 = g0;
+                const dim3 ggrid(per_g * std::min(chunk, groups - g0));
+                if (sd.group == 4 && Rg >= 12)
+                    hipLaunchKernelGGL((k_sor_group<12, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
+                else if (sd.group == 4 && Rg >= 10)
+                    hipLaunchKernelGGL((k_sor_group<10, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
+                else if (sd.group == 4 && Rg >= 8)
+                    hipLaunchKernelGGL((k_sor_group<8, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
+                else if (sd.group == 4)
+                    hipLaunchKernelGGL((k_sor_group<6, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
+                else if (sd.group == 2)
+                    hipLaunchKernelGGL((k_sor_group<8, 2, true>), ggrid, dim3(kLanes * 2), 0, h->stream, Ga);
+                else
+                    return PAPOF_EINVAL;
+            }
             PAPOF_HIP(hipGetLastError());
             mark(0);
             return PAPOF_OK;
@@ -1381,16 +1409,21 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         if (sd.fuse == 2) {  // two sweeps per wave (k_sor_fused); effective pipeline depth R - 2
             const int pairs = (n_sor + 1) / 2;
             A.xcd_affine = (h->sor_xcd_affine && (sd.nb <= 8 || h->sor_xcd_affine > 1)) ? 1 : 0;
-            const dim3 fgrid(A.xcd_affine ? 8 * ((sd.nb + 7) / 8) * pairs : sd.nb * pairs);
+            const int per_q = A.xcd_affine ? 8 * ((sd.nb + 7) / 8) : sd.nb;  // workgroups per pair of sweeps
             const int Rf = h->sor_depth > 0 ? h->sor_depth : 6;
-            if (Rf <= 6)
-                hipLaunchKernelGGL((k_sor_fused<6, true>), fgrid, dim3(kLanes), 0, h->stream, A);
-            else if (Rf <= 8)
-                hipLaunchKernelGGL((k_sor_fused<8, true>), fgrid, dim3(kLanes), 0, h->stream, A);
-            else if (Rf <= 10)
-                hipLaunchKernelGGL((k_sor_fused<10, true>), fgrid, dim3(kLanes), 0, h->stream, A);
-            else
-                hipLaunchKernelGGL((k_sor_fused<12, true>), fgrid, dim3(kLanes), 0, h->stream, A);
+            const int chunk = std::max(1, resident_tasks(h) / per_q);
+            for (int q0 = 0; q0 < pairs; q0 += chunk) {
+                A.k0 = q0;
+                const dim3 fgrid(per_q * std::min(chunk, pairs - q0));
+                if (Rf <= 6)
+                    hipLaunchKernelGGL((k_sor_fused<6, true>), fgrid, dim3(kLanes), 0, h->stream, A);
+                else if (Rf <= 8)
+                    hipLaunchKernelGGL((k_sor_fused<8, true>), fgrid, dim3(kLanes), 0, h->stream, A);
+                else if (Rf <= 10)
+                    hipLaunchKernelGGL((k_sor_fused<10, true>), fgrid, dim3(kLanes), 0, h->stream, A);
+                else
+                    hipLaunchKernelGGL((k_sor_fused<12, true>), fgrid, dim3(kLanes), 0, h->stream, A);
+            }
             PAPOF_HIP(hipGetLastError());
             mark(0);
             return PAPOF_OK;
@@ -1398,24 +1431,30 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         // measured: with at most one band per XCD the affinity is worth 3-4 % (small pyramid levels); beyond that the
         // uneven band count per XCD costs more than the L2 hits give (1920x1080: 18 bands over 8 XCDs, -5 %)
         A.xcd_affine = (h->sor_xcd_affine && (sd.nb <= 8 || h->sor_xcd_affine > 1)) ? 1 : 0;
-        const dim3 grid(A.xcd_affine ? 8 * ((sd.nb + 7) / 8) * n_sor : sd.nb * n_sor), block(kLanes);
+        const int per_k = A.xcd_affine ? 8 * ((sd.nb + 7) / 8) : sd.nb;  // workgroups per sweep
+        const dim3 block(kLanes);
         // pipeline depth: every load is issued R steps ahead and a task looks 2R steps ahead of its producers, so R is
         // also what a hand-off costs.  Measured (profiles/r01_s2_sor_depth_sweep.txt): the big levels want the deeper
         // pipeline (throughput; with the mid-iteration poll 1440x810: 0.85 -> 0.81 ms, 1080x607: 0.68 -> 0.65 ms), the
         // small, hand-off-bound levels the shorter one (607x341: 0.53 -> 0.47 ms).
         const int R = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 8 ? 8 : 6);
-        if (!h->use_dpp)
-            hipLaunchKernelGGL((k_sor_exact<8, false>), grid, block, 0, h->stream, A);
-        else if (R <= 4)
-            hipLaunchKernelGGL((k_sor_exact<4, true>), grid, block, 0, h->stream, A);
-        else if (R <= 6)
-            hipLaunchKernelGGL((k_sor_exact<6, true>), grid, block, 0, h->stream, A);
-        else if (R <= 8)
-            hipLaunchKernelGGL((k_sor_exact<8, true>), grid, block, 0, h->stream, A);
-        else if (R <= 10)
-            hipLaunchKernelGGL((k_sor_exact<10, true>), grid, block, 0, h->stream, A);
-        else
-            hipLaunchKernelGGL((k_sor_exact<12, true>), grid, block, 0, h->stream, A);
+        const int chunk = std::max(1, resident_tasks(h) / per_k);
+        for (int k0 = 0; k0 < n_sor; k0 += chunk) {
+            A.k0 = k0;
+            const dim3 grid(per_k * std::min(chunk, n_sor - k0));
+            if (!h->use_dpp)
+                hipLaunchKernelGGL((k_sor_exact<8, false>), grid, block, 0, h->stream, A);
+            else if (R <= 4)
+                hipLaunchKernelGGL((k_sor_exact<4, true>), grid, block, 0, h->stream, A);
+            else if (R <= 6)
+                hipLaunchKernelGGL((k_sor_exact<6, true>), grid, block, 0, h->stream, A);
+            else if (R <= 8)
+                hipLaunchKernelGGL((k_sor_exact<8, true>), grid, block, 0, h->stream, A);
+            else if (R <= 10)
+                hipLaunchKernelGGL((k_sor_exact<10, true>), grid, block, 0, h->stream, A);
+            else
+                hipLaunchKernelGGL((k_sor_exact<12, true>), grid, block, 0, h->stream, A);
+        }
         PAPOF_HIP(hipGetLastError());
         mark(0);
         return PAPOF_OK;

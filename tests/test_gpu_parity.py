@@ -206,6 +206,65 @@ def test_config4_schedule_and_modes(gpu, oracle):
             _cmp("cfg4 mode%d %s" % (mode, name), g, w_, TOL_SOLVE)
 
 
+def test_config2_480x270_jacobi_matches_oracle(gpu, oracle):
+    """BASELINE.json configs[1]: 480x270 pair, Jacobi inner solver replacing SOR (correctness gate), at ITS size: the
+    whole call (5 levels, reference schedule outer 7+k / sweeps 30+3k) against the oracle run in the same mode.
+    omega = 1: plain Jacobi (an over-relaxed Jacobi iteration diverges)."""
+    from papteam_opticalflow_amd import default_params
+    a, b = cases.load_pair("480")
+    got = gpu.coarse2fine_flow(a, b, 5, default_params(sor_mode=2, omega=1.0))[:3]
+    p = oracle.default_params()
+    p.sor_mode, p.omega = 2, 1.0
+    want = oracle.coarse2fine_flow(a, b, 5, p)[:3]
+    for name, g, w_ in zip(("vx", "vy", "warpI2"), got, want):
+        _cmp("config2 480x270 jacobi %s" % name, g, w_, TOL_SOLVE)
+    gold = np.load(os.path.join(GOLD, "golden.npz"))
+    if "e2e_480_L5|vx" in gold.files:
+        print("   distance of Jacobi (omega 1) to the reference order (subsample): %.3e" %
+              np.abs(cases.subsample(got[0]) - gold["e2e_480_L5|vx"]).max())
+
+
+def test_config3_960x540_redblack_matches_oracle(gpu, oracle):
+    """BASELINE.json configs[2]: 960x540 pair, red-black SOR (LDS-tiled, temporally blocked kernel), full outer / inner
+    fixed-point schedule of the reference (outer 7+k, inner 1, sweeps 30+3k, 5 levels), against the oracle in the same
+    mode -- not against itself.  The distance to the reference's lexicographic order is printed, never asserted
+    (red-black is a throughput mode, not reference parity)."""
+    from papteam_opticalflow_amd import default_params
+    a, b = cases.load_pair("960")
+    got = gpu.coarse2fine_flow(a, b, 5, default_params(sor_mode=1))[:3]
+    p = oracle.default_params()
+    p.sor_mode = 1
+    want = oracle.coarse2fine_flow(a, b, 5, p)[:3]
+    for name, g, w_ in zip(("vx", "vy", "warpI2"), got, want):
+        _cmp("config3 960x540 red-black %s" % name, g, w_, TOL_SOLVE)
+    gold = np.load(os.path.join(GOLD, "golden.npz"))
+    d = max(np.abs(cases.subsample(got[0]) - gold["e2e_960_L5|vx"]).max(),
+            np.abs(cases.subsample(got[1]) - gold["e2e_960_L5|vy"]).max())
+    print("   distance of red-black to the reference order (subsample): %.3e" % d)
+
+
+@pytest.mark.parametrize("mode,omega", [(1, 1.8), (2, 1.0)])
+@pytest.mark.parametrize("h,w,n_sor", [(1080, 1920, 30), (540, 960, 33), (341, 607, 42), (270, 480, 7), (129, 3, 2),
+                                        (3, 300, 5), (49, 127, 11), (48, 128, 10), (97, 257, 1)])
+def test_sor_blocked_kernels_match_oracle_at_size(gpu, oracle, mode, omega, h, w, n_sor):
+    """The LDS-tiled, temporally blocked red-black / Jacobi kernel (sor.hip k_sor_blocked) at the sizes of every pyramid
+    level it runs on, up to 1080p x 30 sweeps, bit for bit against the oracle in the same mode."""
+    planes = _sor_planes(h, w, 5 * h + w)
+    du, dv = gpu.sor(*planes, n_sor, omega=omega, mode=mode)
+    eu, ev = oracle.sor(*planes, n_sor, omega=omega, mode=mode)
+    assert np.array_equal(du, eu) and np.array_equal(dv, ev), (mode, h, w, n_sor, np.abs(du - eu).max())
+
+
+def test_sor_exact_more_tasks_than_the_chip_keeps_resident(gpu, oracle):
+    """Forward progress beyond co-residency: 1080 rows x 200 sweeps = 21 bands x 200 = 4200 one-wave tasks, more than the
+    3072 waves the chip holds at the kernel's occupancy.  sor_solve issues such a solve as consecutive launches of at
+    most 8 tasks per CU (ranges of sweeps); the result must still be the reference's bits."""
+    planes = _sor_planes(1080, 64, 31)
+    du, dv = gpu.sor(*planes, 200, mode=0)
+    eu, ev = oracle.sor(*planes, 200, mode=0)
+    assert np.array_equal(du, eu) and np.array_equal(dv, ev)
+
+
 def test_full_size_properties(gpu):
     """Size-independent properties at BASELINE.json's full 1920x1080 size."""
     a, b = cases.load_pair("1920")
@@ -268,18 +327,21 @@ def test_pyflow_dropin_entry_point(oracle):
 @pytest.mark.parametrize("knob,value", [("PAPOF_SOR_GROUP", "2"), ("PAPOF_SOR_GROUP", "4"), ("PAPOF_SOR_DEPTH", "4"),
                                         ("PAPOF_SOR_DEPTH", "8"), ("PAPOF_SOR_DEPTH", "12"), ("PAPOF_SOR_XCD", "0"),
                                         ("PAPOF_SOR_XCD", "2"), ("PAPOF_OVERLAP", "0"), ("PAPOF_SOR_XLANE", "shfl"),
-                                        ("PAPOF_SOR_FUSE", "2"), ("PAPOF_SOR_FUSE", "1"), ("PAPOF_SOR_FUSE+DEPTH", "2+10")])
+                                        ("PAPOF_SOR_FUSE", "2"), ("PAPOF_SOR_FUSE", "1"), ("PAPOF_SOR_FUSE+DEPTH", "2+10"),
+                                        ("PAPOF_SOR_RESIDENT", "24"), ("PAPOF_SOR_RESIDENT+FUSE", "24+2"),
+                                        ("PAPOF_SOR_RESIDENT+GROUP", "24+4")])
 def test_every_solver_variant_matches_oracle(oracle, knob, value, monkeypatch):
     """Every tuning knob selects code that must give the reference's bits too: the opt-in grouped solver
     (PAPOF_SOR_GROUP: M sweeps of a band per workgroup, LDS hand-off; sor.hip k_sor_group), the pipeline depths the
     size heuristic does not pick, the XCD mappings, the single-stream orchestration, the ds_bpermute lane shifts, and
     the fused kernel (PAPOF_SOR_FUSE=2: two sweeps per wave, k_sor_fused; even and odd sweep counts, one and many bands)
-    forced on for every size / forced off."""
+    forced on for every size / forced off; PAPOF_SOR_RESIDENT: a solve split into many consecutive launches over ranges
+    of sweeps (what sor_solve does when a solve has more tasks than the chip keeps resident), for all three kernels."""
     from papteam_opticalflow_amd import Papof
     group = knob + "=" + value
-    if knob == "PAPOF_SOR_FUSE+DEPTH":
-        monkeypatch.setenv("PAPOF_SOR_FUSE", value.split("+")[0])
-        monkeypatch.setenv("PAPOF_SOR_DEPTH", value.split("+")[1])
+    if "+" in knob:  # two knobs at once
+        for kn, va in zip(knob[len("PAPOF_SOR_"):].split("+"), value.split("+")):
+            monkeypatch.setenv("PAPOF_SOR_" + kn, va)
     else:
         monkeypatch.setenv(knob, value)
     g = Papof(0)  # the environment is read when the handle is created

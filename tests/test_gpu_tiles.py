@@ -70,6 +70,20 @@ def test_tiled_ragged_sizes_and_schedule(gpu, oracle):
         assert np.abs(g - w).max() <= 1e-9, name
 
 
+def test_tiled_2x4_matches_the_oracle_itself(gpu, oracle):
+    """BASELINE.json configs[4] geometry (2 x 4 tiles, LOCAL transport) compared with the ORACLE run in the same
+    (red-black) mode -- not only with the one-GPU result: 480x270 pair, config-4 schedule (3 outer / 30 sweeps), 5 levels."""
+    a, b = cases.load_pair("480")
+    kw = dict(n_outer=3, n_outer_per_level=0, n_sor=30, n_sor_per_level=0)
+    (vx, vy, wi, _), _ = _run_tiles(8, 2, 4, 10, a, b, 5, _params(**kw))
+    p = oracle.default_params()
+    for k, v in dict(kw, sor_mode=1).items():
+        setattr(p, k, v)
+    want = oracle.coarse2fine_flow(a, b, 5, p)[:3]
+    for name, g, w in zip(("vx", "vy", "warpI2"), (vx, vy, wi), want):
+        assert np.array_equal(g, w), "%s: max-abs %.3e" % (name, np.abs(g - w).max())
+
+
 def test_tiled_config4_schedule_full_hd_tile_grid(gpu):
     """BASELINE.json configs[4] geometry (2 x 4 tiles) with the config-4 schedule at 960x540 (full HD is the bench)."""
     a, b = cases.load_pair("960")

@@ -94,3 +94,20 @@ def test_sor_modes_are_distinct_and_deterministic(oracle):
     ex_l = oracle.sor(phi, imdxy, imdx2, imdy2, r1, r2, 3000, mode=0)
     rb_l = oracle.sor(phi, imdxy, imdx2, imdy2, r1, r2, 3000, mode=1)
     assert np.abs(ex_l[0] - rb_l[0]).max() < 1e-9
+
+
+def test_recomposed_level_loop_equals_the_reference_entry_point():
+    """The cfg4_*, ratio* and inner2 goldens come from `ref_coarse2fine_flow_sched` (oracle/ref_driver.cpp), a
+    re-composition of the reference's level loop out of its public statics -- the only way to run the untouched
+    reference with another schedule.  This pins that re-composition to the reference's own entry point: with the
+    reference's hard-coded schedule (outer 7 + k, inner 1, sweeps 30 + 3k, src/OpticalFlow.cpp:747-751, :823) it must
+    return `OpticalFlow::Coarse2FineFlow`'s bits.  Container only: needs the compiled reference (oracle/_ref)."""
+    from _libs import RefLib
+    if not RefLib.available():
+        pytest.skip("oracle/_ref/libpapof_ref.so not built (the reference exists in the build container only)")
+    ref = RefLib()
+    a, b = cases.load_pair("240")
+    for levels in (1, 3, 5):
+        vx, vy, wi, _ = ref.coarse2fine_flow(a, b, levels)
+        sx, sy, sw = ref.coarse2fine_flow_sched(a, b, levels, 0.012, 0.75, 7, 1, 1, 30, 3)
+        assert np.array_equal(vx, sx) and np.array_equal(vy, sy) and np.array_equal(wi, sw), levels
