@@ -679,6 +679,9 @@ int papof_create(int device, papof_handle** out) {
     if (const char* cs = std::getenv("PAPOF_SOR_FUSE")) h->sor_fuse = std::max(1, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_SOR_GROUP")) h->sor_group = std::max(1, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_SOR_XCD")) h->sor_xcd_affine = std::atoi(cs);
+    if (const char* cs = std::getenv("PAPOF_RB_DEPTH")) h->rb_depth = std::max(0, std::atoi(cs));
+    if (const char* cs = std::getenv("PAPOF_RB_SHAPE")) h->rb_shape = std::max(0, std::atoi(cs));
+    if (const char* cs = std::getenv("PAPOF_RB_NAIVE")) h->rb_naive = std::atoi(cs) != 0;
     if (const char* cs = std::getenv("PAPOF_SOR_RESIDENT")) h->sor_resident = std::max(0, std::atoi(cs));
     int rc = sor_probe_dpp(h);
     if (rc != PAPOF_OK) {

@@ -165,7 +165,7 @@ inline void skew_capacity(int h, int w, int n_sor, size_t& cells, size_t& cells_
 struct SorPlanes {
     double *phi, *xy, *a1, *a2, *b1, *b2;  // weights, imdxy, omega/diag_u, omega/diag_v, rhs_u, rhs_v
     double *du, *dv;                       // unknowns (written from zero; no initialisation needed)
-    double *du2, *dv2;                     // Jacobi ping-pong (row-major modes only)
+    double *du2, *dv2;                     // second pair of unknown planes (row-major modes only): launches alternate
     bool skew;
     SkewDims sd;                           // skew mode: layout bound by sor_bind() for (H, W, n_sor) of this solve
     size_t cap_cells, cap_cells_d;         // skew mode: cells the coefficient planes / the (du, dv) allocation can hold
@@ -248,6 +248,9 @@ struct papof_handle {
     void* sor_mark_ctx = nullptr;
     int sor_fuse = 0;                // sweeps per wave of the exact-order solver: 1 or 2; 0 = by problem size
     int sor_group = 0;               // consecutive sweeps of a band per workgroup: 1, 2 or 4; 0 = by problem size
+    int rb_depth = 0;                // blocked red-black / Jacobi solver: half-sweeps per launch; 0 = by region shape
+    int rb_shape = 0;                // ... region shape 1..4 (sor.hip: blocked_shape); 0 = by plane size
+    int rb_naive = 0;                // 1: one launch per half-sweep on the planes (cross-check)
     int sor_resident = 0;            // tasks per launch of the exact-order kernels; 0 = 8 per CU (sor.hip: resident_tasks)
     // second stream for everything that does not depend on the flow (pyramids, features, smoothed frame 1 of every
     // level, derivative planes of the final bicubic warp): runs beside the coarse levels' latency-bound solves
@@ -311,6 +314,9 @@ Taps central3_taps();
 int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor, int mode);
 int sor_redblack_halfsweep(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int colour,
                            const Rect& r);
+int sor_blocked_depth(const papof_handle* h, int mode, int H, int W);  // half-sweeps per launch the blocked solver uses
+int sor_blocked_launch(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int mode, int g,
+                       int hs0, const Rect& out, const double* su, const double* sv, double* du, double* dv);
 int sor_check(papof_handle* h);  // after a stream sync: PAPOF_ETIMEOUT if a device-side wait expired
 int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes& sp);  // carve the operand planes
 int sor_bind(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor);  // choose the layout of the next solves (skew mode)

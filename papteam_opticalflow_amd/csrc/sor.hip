@@ -1258,6 +1258,274 @@ __global__ void k_sor_jacobi(const double* __restrict__ phi, const double* __res
     cell_update(phi, xy, a1, a2, b1, b2, ru, rv, wu, wv, i, j, H, W, nalpha, om1);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS-TILED, TEMPORALLY BLOCKED red-black / Jacobi solver (the kernel behind PAPOF_SOR_REDBLACK / _JACOBI and behind
+// the multi-GPU tiles).  Same per-cell arithmetic as cell_update() above (src/OpticalFlow.cpp:458-505), other sweep order.
+//
+// A workgroup owns a REGION of 128 x (NW * RPT) cells = its core tile grown by a ghost ring `g` deep, keeps it on chip
+// and runs g half-sweeps (Jacobi: g sweeps) on it in ONE launch: half-sweep m is exact on the region shrunk by m + 1
+// cells from every edge that is not an image border (a cell one ring further out misses a neighbour one step earlier --
+// the same ghost-zone algebra tiles.hip uses between GPUs), so after g half-sweeps the core tile is exact and is the
+// only part written back.  The six coefficient planes are read ONCE per g half-sweeps (the naive kernels read them once
+// per half-sweep) with full-line coalesced row loads (16 bytes per lane where rows are 16-byte aligned), never with
+// stride 2; a 30-sweep solve is ceil(60 / g) launches instead of 60.
+//   * ownership: lane t of wave w owns columns 2t, 2t+1 of the RPT rows w*RPT .. w*RPT+RPT-1 of the region: one cell of
+//     each colour per row, so every lane has the same work in every half-sweep.  Its coefficients stay in REGISTERS for
+//     the whole launch: per row three weights phi(j0-1), phi(j0), phi(j0+1) (the left weight of the right cell is the
+//     centre weight of the left one; the upper weights are the row above's centre weights) and five doubles per cell
+//     (imdxy, omega/diag_u, omega/diag_v, rhs_u, rhs_v): 13 * RPT + 2 doubles per lane.
+//   * the unknowns live in LDS as 16-byte (du, dv) cells in two COLOUR-SPLIT arrays [colour][row][t]: a half-sweep of
+//     colour c reads own / left / right / up / down = lds[c][r][t], lds[1-c][r][t-1+p], [r][t+p], [r-1][t], [r+1][t]
+//     (p = parity of the cell's column in the lane's pair) -- consecutive lanes touch consecutive 16-byte cells, so every
+//     ds_read_b128 / ds_write_b128 is bank-conflict free; rows are padded by one zero cell and the array by a zero row
+//     above and below, cells outside the image hold (0, 0): border terms become +-0 added in the reference's order, no
+//     predicates.  A colour-c half-sweep writes only colour-c cells, each by its owner, and reads colour 1-c cells: one
+//     workgroup barrier per half-sweep.  (Jacobi: all new values of a sweep in registers, barrier, write, barrier.)
+//   * results go to the OTHER pair of (du, dv) planes (neighbouring workgroups still read the old ghost cells): the host
+//     alternates the pairs and arranges that the last launch lands in sp.du / sp.dv.  The first launch of a solve reads
+//     no unknowns at all (du = dv = 0, src/OpticalFlow.cpp:452-453).
+// ------------------------------------------------------------------------------------------------
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+struct BlockedArgs {
+    const double *phi, *xy, *a1, *a2, *b1, *b2;
+    const double *su, *sv;  // unknowns before this launch (null: all zero)
+    double *du, *dv;        // unknowns after it (another pair of planes)
+    int H, W;
+    Rect out;               // cells this launch must deliver (the whole plane on one GPU)
+    int g;                  // half-sweeps (Jacobi: sweeps) of this launch = ghost depth
+    int hs0;                // index of the first half-sweep of this launch within the solve (its parity = its colour)
+    int cw, ch, ntx, nblk;  // core tile size, tiles per row, tiles
+    int shift;              // 1: regions start one column further left, so that every region starts on an even column
+    double nalpha, om1;
+};
+
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ f64x2 load_pair(const double* __restrict__ plane, size_t o, bool ok0, bool ok1) {
+    f64x2 r = {0.0, 0.0};
+    if (VEC) {  // 16-byte aligned by construction (even row pitch, even first column)
+        if (ok0) r = *reinterpret_cast<const f64x2*>(plane + o);
+    } else {
+        if (ok0) r.x = plane[o];
+        if (ok1) r.y = plane[o + 1];
+    }
+    return r;
+}
+
+template <int MODE, int NW, int RPT, bool VEC>
+__global__ __launch_bounds__(NW * 64) void k_sor_blocked(BlockedArgs A) {
+    constexpr int RH = NW * RPT, S = kLanes + 1, CELLS = (RH + 2) * S + 2;
+    __shared__ f64x2 lds[2][CELLS];
+    const int t = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // Workgroups are dealt round-robin over the 8 XCDs (observed; speed only): give each XCD a contiguous run of tiles so
+    // that the ghost cells two neighbouring tiles both read are found in that XCD's L2.
+    const int per = (A.nblk + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || tile >= A.nblk) return;  // whole workgroup, before any barrier
+    const int by = tile / A.ntx, bx = tile - by * A.ntx;
+    const int cx0 = A.out.x0 + bx * A.cw, cx1 = min(cx0 + A.cw, A.out.x1);
+    const int cy0 = A.out.y0 + by * A.ch, cy1 = min(cy0 + A.ch, A.out.y1);
+    const int rx0 = max(0, cx0 - A.g - A.shift), rx1 = min(A.W, cx1 + A.g);
+    const int ry0 = max(0, cy0 - A.g), ry1 = min(A.H, cy1 + A.g);
+    const int W = A.W;
+    const int j0 = rx0 + 2 * t;      // this lane's columns: j0, j0 + 1
+    const int r0 = w * RPT;          // first region row of this wave
+    const int q0 = (ry0 + rx0 + r0) & 1;  // colour of cell (row r0, column j0)
+
+    // ---- coefficients -> registers
+    double ph[RPT][3], up[2], cxy[RPT][2], ca1[RPT][2], ca2[RPT][2], cb1[RPT][2], cb2[RPT][2];
+    f64x2 u0[RPT], v0[RPT];
+    {
+        const int iu = ry0 + r0 - 1;  // the row above this wave's rows: only its weights are needed
+        const bool rok = iu >= 0 && iu < ry1;
+        const f64x2 pu = load_pair<VEC>(A.phi, (size_t)max(iu, 0) * W + j0, rok && j0 < rx1, rok && j0 + 1 < rx1);
+        up[0] = pu.x;
+        up[1] = pu.y;
+    }
+    static_for<RPT>([&](auto RR) __attribute__((always_inline)) {
+        constexpr int rr = decltype(RR)::value;
+        const int i = ry0 + r0 + rr;
+        const bool rok = i < ry1, ok0 = rok && j0 < rx1, ok1 = rok && j0 + 1 < rx1;
+        const size_t o = (size_t)min(i, A.H - 1) * W + j0;
+        const f64x2 p = load_pair<VEC>(A.phi, o, ok0, ok1);
+        const f64x2 x = load_pair<VEC>(A.xy, o, ok0, ok1);
+        const f64x2 q1 = load_pair<VEC>(A.a1, o, ok0, ok1);
+        const f64x2 q2 = load_pair<VEC>(A.a2, o, ok0, ok1);
+        const f64x2 e1 = load_pair<VEC>(A.b1, o, ok0, ok1);
+        const f64x2 e2 = load_pair<VEC>(A.b2, o, ok0, ok1);
+        u0[rr] = f64x2{0.0, 0.0};
+        v0[rr] = f64x2{0.0, 0.0};
+        if (A.su) {  // wave-uniform
+            u0[rr] = load_pair<VEC>(A.su, o, ok0, ok1);
+            v0[rr] = load_pair<VEC>(A.sv, o, ok0, ok1);
+        }
+        ph[rr][1] = p.x;
+        ph[rr][2] = p.y;
+        cxy[rr][0] = x.x;
+        cxy[rr][1] = x.y;
+        ca1[rr][0] = q1.x;
+        ca1[rr][1] = q1.y;
+        ca2[rr][0] = q2.x;
+        ca2[rr][1] = q2.y;
+        cb1[rr][0] = e1.x;
+        cb1[rr][1] = e1.y;
+        cb2[rr][0] = e2.x;
+        cb2[rr][1] = e2.y;
+    });
+    // the weight left of the lane's left cell is the centre weight of the previous lane's right cell (lane 0: column
+    // rx0 - 1, needed only where column rx0 is updated, i.e. at the image border, where that term is +-0 anyway)
+    static_for<RPT>([&](auto RR) __attribute__((always_inline)) {
+        constexpr int rr = decltype(RR)::value;
+        const double left = __shfl_up(ph[rr][2], 1);
+        ph[rr][0] = t == 0 ? 0.0 : left;
+    });
+
+    // ---- unknowns -> LDS (colour-split), pads -> 0
+    const int idx0 = (r0 + 1) * S + t + 1;  // cell index of (row r0, this lane) in either colour array
+    static_for<RPT>([&](auto RR) __attribute__((always_inline)) {
+        constexpr int rr = decltype(RR)::value;
+        const int c0 = (q0 + rr) & 1;  // colour of the lane's LEFT cell in this row
+        lds[c0][idx0 + rr * S] = f64x2{u0[rr].x, v0[rr].x};
+        lds[c0 ^ 1][idx0 + rr * S] = f64x2{u0[rr].y, v0[rr].y};
+        if (t == 0) {  // the pad cell in front of this row (= behind the previous one)
+            lds[0][idx0 + rr * S - 1] = f64x2{0.0, 0.0};
+            lds[1][idx0 + rr * S - 1] = f64x2{0.0, 0.0};
+        }
+    });
+    if (w == 0) {  // pad row above the region: indices 0 .. S-1
+        lds[0][t] = f64x2{0.0, 0.0};
+        lds[1][t] = f64x2{0.0, 0.0};
+        if (t == 0) {
+            lds[0][S - 1] = f64x2{0.0, 0.0};
+            lds[1][S - 1] = f64x2{0.0, 0.0};
+        }
+    }
+    if (w == NW - 1) {  // pad row below: indices (RH+1)*S .. (RH+1)*S + S (its own pad cell and the trailing one included)
+        lds[0][(RH + 1) * S + t] = f64x2{0.0, 0.0};
+        lds[1][(RH + 1) * S + t] = f64x2{0.0, 0.0};
+        if (t < 3) {
+            lds[0][(RH + 1) * S + 64 + t - 1 + 1] = f64x2{0.0, 0.0};
+            lds[1][(RH + 1) * S + 64 + t - 1 + 1] = f64x2{0.0, 0.0};
+        }
+    }
+    __syncthreads();
+
+    // ---- the sweeps
+    const int ox0 = rx0 > 0, ox1 = rx1 < A.W, oy0 = ry0 > 0, oy1 = ry1 < A.H;  // 1 where the region edge is open
+    const int rw = rx1 - rx0, rh = ry1 - ry0;
+    const double nalpha = A.nalpha, om1 = A.om1;
+    // one cell: row r0 + rr, column pair member p, colour array `cc`; returns the new (du, dv)
+    const auto cell = [&](auto RR, auto PP, int cc) __attribute__((always_inline)) -> f64x2 {
+        constexpr int rr = decltype(RR)::value, p = decltype(PP)::value;
+        const int idx = idx0 + rr * S;
+        const f64x2* __restrict__ Lo = lds[cc ^ 1];
+        const f64x2 own = lds[cc][idx];
+        const f64x2 L = Lo[idx - 1 + p], R = Lo[idx + p], U = Lo[idx - S], D = Lo[idx + S];
+        const double pc = ph[rr][1 + p], wl = ph[rr][p];
+        double wu;
+        if constexpr (rr > 0)
+            wu = ph[rr - 1][1 + p];
+        else
+            wu = up[p];
+        double s1 = wl * L.x, s2 = wl * L.y;
+        s1 += pc * R.x;
+        s2 += pc * R.y;
+        s1 += wu * U.x;
+        s2 += wu * U.y;
+        s1 += pc * D.x;
+        s2 += pc * D.y;
+        s1 *= nalpha;
+        s2 *= nalpha;
+        s1 += cxy[rr][p] * own.y;
+        const double nu = om1 * own.x + ca1[rr][p] * (cb1[rr][p] - s1);
+        s2 += cxy[rr][p] * nu;
+        const double nv = om1 * own.y + ca2[rr][p] * (cb2[rr][p] - s2);
+        return f64x2{nu, nv};
+    };
+    if (MODE == PAPOF_SOR_REDBLACK) {
+        // PAR = parity of (q0 + colour): the member of the lane's pair that has the half-sweep's colour in row rr is
+        // p = (PAR + rr) & 1 -- a compile-time constant inside each of the two instantiations
+        const auto half = [&](auto PARC, int m, int c) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(PARC)::value;
+            const int fx0 = ox0 * (m + 1), fx1 = rw - ox1 * (m + 1), fy0 = oy0 * (m + 1), fy1 = rh - oy1 * (m + 1);
+            static_for<RPT>([&](auto RR) __attribute__((always_inline)) {
+                constexpr int rr = decltype(RR)::value;
+                constexpr int p = (PAR + rr) & 1;
+                const int r = r0 + rr;
+                if (r >= fy0 && r < fy1) {  // wave-uniform
+                    const f64x2 nw = cell(RR, std::integral_constant<int, p>{}, c);
+                    const int lc = 2 * t + p;
+                    if (lc >= fx0 && lc < fx1) lds[c][idx0 + rr * S] = nw;
+                }
+            });
+            __syncthreads();
+        };
+        for (int m = 0; m < A.g; m++) {
+            const int c = (A.hs0 + m) & 1;
+            if ((q0 + c) & 1)
+                half(std::integral_constant<int, 1>{}, m, c);
+            else
+                half(std::integral_constant<int, 0>{}, m, c);
+        }
+    } else {  // Jacobi: every cell from the previous sweep's values
+        for (int m = 0; m < A.g; m++) {
+            const int fx0 = ox0 * (m + 1), fx1 = rw - ox1 * (m + 1), fy0 = oy0 * (m + 1), fy1 = rh - oy1 * (m + 1);
+            f64x2 nw[RPT][2];
+            static_for<RPT>([&](auto RR) __attribute__((always_inline)) {
+                constexpr int rr = decltype(RR)::value;
+                const int c0 = (q0 + rr) & 1;  // colour array of the left cell
+                nw[rr][0] = cell(RR, std::integral_constant<int, 0>{}, c0);
+                nw[rr][1] = cell(RR, std::integral_constant<int, 1>{}, c0 ^ 1);
+            });
+            __syncthreads();
+            static_for<RPT>([&](auto RR) __attribute__((always_inline)) {
+                constexpr int rr = decltype(RR)::value;
+                const int c0 = (q0 + rr) & 1, r = r0 + rr;
+                if (r >= fy0 && r < fy1) {
+                    if (2 * t >= fx0 && 2 * t < fx1) lds[c0][idx0 + rr * S] = nw[rr][0];
+                    if (2 * t + 1 >= fx0 && 2 * t + 1 < fx1) lds[c0 ^ 1][idx0 + rr * S] = nw[rr][1];
+                }
+            });
+            __syncthreads();
+        }
+    }
+
+    // ---- core tile -> the other pair of planes (own cells only: no barrier needed after the last write)
+    static_for<RPT>([&](auto RR) __attribute__((always_inline)) {
+        constexpr int rr = decltype(RR)::value;
+        const int i = ry0 + r0 + rr;
+        if (i >= cy0 && i < cy1) {  // wave-uniform
+            const int c0 = (q0 + rr) & 1;
+            const f64x2 a = lds[c0][idx0 + rr * S], b = lds[c0 ^ 1][idx0 + rr * S];
+            const size_t o = (size_t)i * W + j0;
+            const bool in0 = j0 >= cx0 && j0 < cx1, in1 = j0 + 1 >= cx0 && j0 + 1 < cx1;
+            if (VEC && in0 && in1) {
+                *reinterpret_cast<f64x2*>(A.du + o) = f64x2{a.x, b.x};
+                *reinterpret_cast<f64x2*>(A.dv + o) = f64x2{a.y, b.y};
+            } else {
+                if (in0) {
+                    A.du[o] = a.x;
+                    A.dv[o] = a.y;
+                }
+                if (in1) {
+                    A.du[o + 1] = b.x;
+                    A.dv[o + 1] = b.y;
+                }
+            }
+        }
+    });
+}
+
 }  // namespace
 
 // One colour of a red-black sweep on a region of the (row-major) operand planes.  The whole plane on one GPU; a tile
@@ -1283,6 +1551,137 @@ int sor_redblack_halfsweep(papof_handle* h, const SorPlanes& sp, int H, int W, d
 static int resident_tasks(const papof_handle* h) {
     if (h->sor_resident > 0) return h->sor_resident;
     return std::max(64, (h->cu_count > 0 ? h->cu_count : 256) * 8);
+}
+
+// ---- the blocked solver's host side -------------------------------------------------------------------
+// Region shapes (waves per workgroup x rows per lane; the region is 128 columns x NW * RPT rows).  Registers hold
+// 13 * RPT + 2 doubles of coefficients per lane and LDS 2 * 16 B per cell, so 128 x 48 cells is what one CU can keep
+// (8 waves x 6 rows: 160 + temporaries of 256 VGPRs, 104 KiB LDS); small planes get smaller regions = more workgroups.
+struct BlockedShape {
+    int nw, rpt;
+};
+static BlockedShape blocked_shape_any(const papof_handle* h, int H, int W) {
+    if (h->rb_shape == 1) return {8, 6};
+    if (h->rb_shape == 2) return {8, 4};
+    if (h->rb_shape == 3) return {4, 6};
+    if (h->rb_shape == 4) return {16, 3};
+    // measured (tools/rb_sweep.py, profiles/r02_rb_shape_depth_sweep.txt): 16 waves x 3 rows beats 8 x 6 on every plane
+    // (four waves per SIMD hide the LDS latency of a half-sweep), the smaller 8 x 4 region wins below ~300 k cells (more
+    // workgroups for the same plane)
+    if (W <= 128 && H <= 24) return {4, 6};
+    if (W <= 128 && H <= 32) return {8, 4};
+    if ((size_t)H * W >= (size_t)300 * 1000) return {16, 3};
+    return {8, 4};
+}
+static BlockedShape blocked_shape(const papof_handle* h, int mode, int H, int W) {
+    const BlockedShape bs = blocked_shape_any(h, H, W);
+    // Jacobi keeps a sweep's new values of all 2 * RPT cells in registers beside the coefficients: no 8 x 6 variant
+    if (mode == PAPOF_SOR_JACOBI && ((bs.nw == 8 && bs.rpt == 6) || bs.nw == 16)) return {8, 4};
+    return bs;
+}
+
+int sor_blocked_depth(const papof_handle* h, int mode, int H, int W) {
+    if (h->rb_depth > 0) return h->rb_depth;
+    const BlockedShape bs = blocked_shape(h, mode, H, W);
+    const int rh = bs.nw * bs.rpt;
+    if (mode == PAPOF_SOR_JACOBI) return rh >= 48 ? 8 : (rh >= 32 ? 6 : 4);
+    return rh >= 32 ? 10 : 6;  // half-sweeps: 60 = 6 x 10
+}
+
+// One launch: `g` half-sweeps (Jacobi: sweeps) starting with half-sweep `hs0` of the solve, delivering the cells of `out`;
+// (su, sv) -> (du, dv) must be different pairs of planes; su == null: the unknowns are zero before the launch.
+int sor_blocked_launch(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int mode, int g,
+                       int hs0, const Rect& out, const double* su, const double* sv, double* du, double* dv) {
+    if (sp.skew || g < 1 || (mode != PAPOF_SOR_REDBLACK && mode != PAPOF_SOR_JACOBI)) return PAPOF_EINVAL;
+    if (out.empty()) return PAPOF_OK;
+    if (su == du || sv == dv || !du || !dv) return PAPOF_EINVAL;
+    const BlockedShape bs = blocked_shape(h, mode, out.h(), out.w());  // by the size of what is solved (a tile: tiles.hip)
+    const int RW = 2 * kLanes, RH = bs.nw * bs.rpt;
+    BlockedArgs A;
+    A.phi = sp.phi;
+    A.xy = sp.xy;
+    A.a1 = sp.a1;
+    A.a2 = sp.a2;
+    A.b1 = sp.b1;
+    A.b2 = sp.b2;
+    A.su = su;
+    A.sv = sv;
+    A.du = du;
+    A.dv = dv;
+    A.H = H;
+    A.W = W;
+    A.out = out;
+    A.g = g;
+    A.hs0 = hs0;
+    A.nalpha = -alpha;
+    A.om1 = 1 - omega;
+    // Core tile: the region minus the ghost ring; where `out` reaches an image border no ring is needed on that side, so a
+    // plane that fits one region is ONE workgroup with no ghost cells at all, whatever g.
+    const bool span_x = out.x0 == 0 && out.x1 == W && W <= RW, span_y = out.y0 == 0 && out.y1 == H && H <= RH;
+    // 16-byte row loads / stores need every region to start on an even column (of an even-pitched plane): tiles are an
+    // even number of columns wide, and where out.x0 - g is odd the regions start one column further left (shift).
+    A.shift = span_x ? 0 : ((out.x0 - g) & 1);
+    A.cw = span_x ? W : RW - 2 * g - 2 * A.shift;
+    A.ch = span_y ? H : RH - 2 * g;
+    if (A.cw < (span_x ? 1 : 2) || A.ch < 1) return PAPOF_EINVAL;  // g too deep for this region shape
+    A.ntx = (out.w() + A.cw - 1) / A.cw;
+    const int nty = (out.h() + A.ch - 1) / A.ch;
+    A.nblk = A.ntx * nty;
+    const bool vec = (W & 1) == 0;
+    const dim3 grid(8 * ((A.nblk + 7) / 8)), block(bs.nw * kLanes);
+#define PAPOF_BLOCKED(MODE, NW, RPT)                                                                       \
+    do {                                                                                                   \
+        if (vec)                                                                                           \
+            hipLaunchKernelGGL((k_sor_blocked<MODE, NW, RPT, true>), grid, block, 0, h->stream, A);       \
+        else                                                                                               \
+            hipLaunchKernelGGL((k_sor_blocked<MODE, NW, RPT, false>), grid, block, 0, h->stream, A);      \
+    } while (0)
+    if (mode == PAPOF_SOR_REDBLACK) {
+        if (bs.nw == 8 && bs.rpt == 6)
+            PAPOF_BLOCKED(PAPOF_SOR_REDBLACK, 8, 6);
+        else if (bs.nw == 8 && bs.rpt == 4)
+            PAPOF_BLOCKED(PAPOF_SOR_REDBLACK, 8, 4);
+        else if (bs.nw == 4 && bs.rpt == 6)
+            PAPOF_BLOCKED(PAPOF_SOR_REDBLACK, 4, 6);
+        else
+            PAPOF_BLOCKED(PAPOF_SOR_REDBLACK, 16, 3);
+    } else {
+        if (bs.nw == 4 && bs.rpt == 6)
+            PAPOF_BLOCKED(PAPOF_SOR_JACOBI, 4, 6);
+        else
+            PAPOF_BLOCKED(PAPOF_SOR_JACOBI, 8, 4);
+    }
+#undef PAPOF_BLOCKED
+    PAPOF_HIP(hipGetLastError());
+    return PAPOF_OK;
+}
+
+// `units` half-sweeps (Jacobi: sweeps) from zero on the whole plane: ceil(units / depth) launches of nearly equal depth,
+// alternating between the two pairs of planes so that the LAST one writes (sp.du, sp.dv).
+static int sor_blocked_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int mode,
+                             int units) {
+    if (!sp.du2 || !sp.dv2) return PAPOF_EINVAL;
+    const BlockedShape bs = blocked_shape(h, mode, H, W);
+    const bool one_block = W <= 2 * kLanes && H <= bs.nw * bs.rpt;
+    // Red-black: launches hold whole sweeps (an even number of half-sweeps) whenever the depth allows
+    const int q = (mode == PAPOF_SOR_REDBLACK && units % 2 == 0) ? 2 : 1;  // half-sweeps per planning unit
+    const int n_units = units / q;
+    const int depth = one_block ? n_units : std::max(1, sor_blocked_depth(h, mode, H, W) / q);
+    const int n_launch = (n_units + depth - 1) / depth, base = n_units / n_launch, rem = n_units % n_launch;
+    const Rect all{0, 0, W, H};
+    const double *su = nullptr, *sv = nullptr;
+    bool to_main = (n_launch & 1) != 0;  // odd count: start in the main pair, so that the last launch ends there too
+    int done = 0;
+    for (int l = 0; l < n_launch; l++) {
+        const int g = q * (base + (l < rem ? 1 : 0));
+        double *du = to_main ? sp.du : sp.du2, *dv = to_main ? sp.dv : sp.dv2;
+        PAPOF_TRY(sor_blocked_launch(h, sp, H, W, alpha, omega, mode, g, done, all, su, sv, du, dv));
+        su = du;
+        sv = dv;
+        done += g;
+        to_main = !to_main;
+    }
+    return PAPOF_OK;
 }
 
 int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor, int mode) {
@@ -1460,6 +1859,13 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         return PAPOF_OK;
     }
     if (sp.skew) return PAPOF_EINVAL;
+    if (!h->rb_naive) {  // the LDS-tiled, temporally blocked kernel: no plane clears (the first launch reads no unknowns)
+        mark(1);
+        PAPOF_TRY(sor_blocked_solve(h, sp, H, W, alpha, omega, mode, mode == PAPOF_SOR_REDBLACK ? 2 * n_sor : n_sor));
+        mark(0);
+        return PAPOF_OK;
+    }
+    // PAPOF_RB_NAIVE=1: one launch per half-sweep straight on the planes (the first implementation; kept as a cross-check)
     const size_t np = (size_t)H * W;
     PAPOF_HIP(hipMemsetAsync(sp.du, 0, np * sizeof(double), h->stream));  // src/OpticalFlow.cpp:452-453
     PAPOF_HIP(hipMemsetAsync(sp.dv, 0, np * sizeof(double), h->stream));
@@ -1564,10 +1970,8 @@ int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes&
         sp.b2 = A.f64(n);
         sp.du = A.f64(n);
         sp.dv = A.f64(n);
-        if (mode == PAPOF_SOR_JACOBI) {
-            sp.du2 = A.f64(n);
-            sp.dv2 = A.f64(n);
-        }
+        sp.du2 = A.f64(n);  // second pair of unknown planes: the blocked solver / Jacobi alternate between the two
+        sp.dv2 = A.f64(n);
     }
     return A.overflow ? PAPOF_ENOMEM : PAPOF_OK;
 }

@@ -463,18 +463,38 @@ int tiles_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
             PAPOF_TRY(assemble_system(h, blend, imdt, phi, u, v, lh, lw, fc, P.alpha, P.omega, sp, nullptr, nullptr,
                                       nullptr, &Rsys));
             sorclk.phase(PAPOF_T_PHASE5_SOR);
-            PAPOF_HIP(hipMemsetAsync(sp.du, 0, np * sizeof(double), h->stream));  // src/OpticalFlow.cpp:452-453
-            PAPOF_HIP(hipMemsetAsync(sp.dv, 0, np * sizeof(double), h->stream));
-            double* dd[2] = {sp.du, sp.dv};
+            // The solve, from du = dv = 0 (src/OpticalFlow.cpp:452-453): periods of S half-sweeps between exchanges.  A
+            // period of s half-sweeps is one or more launches of the LDS-tiled, temporally blocked kernel (sor.hip): a
+            // launch of depth g that must deliver region R reads R grown by g, so the launches of a period deliver the
+            // tile grown by s - (half-sweeps done) -- the shrinking frame of the ghost-zone scheme, g rings at a time.
+            // Launches alternate between the two pairs of (du, dv) planes; an exchange fills the ghost ring of the pair
+            // the next launch reads.  The first period reads no unknowns at all.
             const int n_half = 2 * n_sor;
-            for (int hs = 0; hs < n_half; hs++) {
-                const int m = hs % S;
-                const Rect R = grow(T, S - 1 - m, lw, lh);
-                PAPOF_TRY(sor_redblack_halfsweep(h, spt, lh, lw, P.alpha, P.omega, hs & 1, R));
-                if (m == S - 1 && hs != n_half - 1) PAPOF_TRY(exchange_planes(t, dd, 2, lw, own, need_d));
+            const int gmax = std::max(2, sor_blocked_depth(h, PAPOF_SOR_REDBLACK, T.h(), T.w()));
+            const double *su = nullptr, *sv = nullptr;
+            for (int hs = 0; hs < n_half;) {
+                const int s = std::min(S, n_half - hs);
+                for (int done = 0; done < s;) {
+                    const int g = std::min(gmax, s - done);
+                    const Rect R = grow(T, s - done - g, lw, lh);
+                    double *du = su == sp.du ? sp.du2 : sp.du, *dv = sv == sp.dv ? sp.dv2 : sp.dv;
+                    PAPOF_TRY(sor_blocked_launch(h, spt, lh, lw, P.alpha, P.omega, PAPOF_SOR_REDBLACK, g, hs + done, R, su, sv,
+                                                 du, dv));
+                    su = du;
+                    sv = dv;
+                    done += g;
+                }
+                hs += s;
+                if (hs < n_half) {
+                    double* dd[2] = {const_cast<double*>(su), const_cast<double*>(sv)};
+                    PAPOF_TRY(exchange_planes(t, dd, 2, lw, own, need_d));
+                }
             }
             sorclk.phase(-1);
-            PAPOF_TRY(update_flow(h, sp, u, v, lh, lw, T));  // :513-514
+            SorPlanes spc = sp;  // the pair of planes that holds the increments now
+            spc.du = const_cast<double*>(su);
+            spc.dv = const_cast<double*>(sv);
+            PAPOF_TRY(update_flow(h, spc, u, v, lh, lw, T));  // :513-514
             double* uv[2] = {u, v};
             PAPOF_TRY(exchange_planes(t, uv, 2, lw, own, need_u));
             PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc, &Tu));  // :516
