@@ -326,7 +326,13 @@ def main():
         value = world * args.pairs * (h * w / 1e6) / (elapsed / args.steps)
         dims = level_dims(gpu, h, w, args.levels) if gpu is not None else [(w, h)] * args.levels
         updates = sum(lw * lh * (sched[0] + k * sched[1]) * (sched[2] + k * sched[3]) for k, (lw, lh) in enumerate(dims))
-        launches = sum(sched[0] + k * sched[1] for k in range(args.levels)) * (1 if mode == 0 else 0)
+        # solver-kernel launches per step: solves x launches per solve (the exact-order kernels: one per solve unless a
+        # solve exceeds the chip's resident capacity; the blocked red-black / Jacobi kernel: one per `depth` half-sweeps)
+        launches, depths = 0, []
+        for k, (lw, lh) in enumerate(dims):
+            nl, dp = gpu.sor_plan(lh, lw, sched[2] + k * sched[3], mode) if gpu is not None else (1, 1)
+            launches += (sched[0] + k * sched[1]) * nl
+            depths.append(dp)
         sor_step = sor_sec / args.steps
         achieved = updates * BYTES_PER_UPDATE / 1e9 / sor_step if sor_step > 0 else 0.0
         traffic = None
@@ -363,7 +369,9 @@ def main():
                        "pairs_in_flight_per_gpu": args.pairs,
                        "parallelism": "replicas: one independent frame pair per GPU" if world > 1 else "1 GPU"},
             "max_abs_duv_vs_reference": parity,
-            "roofline": {"bound": "hbm", "kernel": "k_sor_exact + k_sor_fused (exact-order SOR solves)" if mode == 0 else "k_sor_" + args.mode,
+            "roofline": {"bound": "hbm", "kernel": "k_sor_exact + k_sor_fused (exact-order SOR solves)" if mode == 0 else
+                         "k_sor_blocked (LDS-tiled, temporally blocked %s solves; %s %s per launch by level)" % (
+                             args.mode, "/".join(str(d) for d in depths), "half-sweeps" if mode == 1 else "sweeps"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches_per_step": launches, "cell_updates_per_step": updates,

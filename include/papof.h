@@ -254,6 +254,11 @@ int papof_flow_to_bgr(papof_handle* h, const double* vx, const double* vy, int h
 int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_mode, int reps, unsigned seed,
                     double* ms_per_solve);
 
+/* Measurement aid for bench.py: how a solve of `n_sor` sweeps on a height x width plane is issued in `sor_mode` on this
+ * handle -- solver-kernel launches per solve, and the sweeps one launch runs (exact order: 1, or 2 with two sweeps per
+ * wave; red-black: HALF-sweeps per launch of the LDS-tiled, temporally blocked kernel; Jacobi: sweeps per launch). */
+int papof_sor_plan(papof_handle* h, int height, int width, int n_sor, int sor_mode, int* launches, int* depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,7 +47,7 @@ SYMBOLS = [
     "papof_seq_push", "papof_seq_push_u8", "papof_seq_push_device", "papof_tiles_grid", "papof_tiles_rect",
     "papof_tiles_halo_message", "papof_tiles_unique_id", "papof_tiles_create", "papof_tiles_create_local",
     "papof_tiles_flow_device", "papof_tiles_stats", "papof_tiles_destroy", "papof_flow_quantize16",
-    "papof_flow_dequantize16", "papof_flow_to_bgr", "papof_set_graph_mode",
+    "papof_flow_dequantize16", "papof_flow_to_bgr", "papof_set_graph_mode", "papof_sor_plan",
 ]
 
 
@@ -126,6 +126,7 @@ def load():
                                          c_int, c_double, c_int]
     L.papof_stage_bicubic_warp.argtypes = [c_void_p, _D, _D, _D, _D, c_int, c_int, c_int, _D]
     L.papof_bench_sor.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, _D]
+    L.papof_sor_plan.argtypes = [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     _lib = L
     return L
 
@@ -427,6 +428,12 @@ class Papof:
         out = np.zeros((h, w, 3), dtype=np.uint8)
         _chk(self.L.papof_flow_to_bgr(self.h, _p(vx), _p(vy), h, w, out.ctypes.data_as(c_void_p)), "papof_flow_to_bgr")
         return out
+
+    def sor_plan(self, h, w, n_sor, mode=SOR_EXACT):
+        """(solver-kernel launches per solve, sweeps [red-black: half-sweeps] per launch) on this handle"""
+        nl, d = c_int(0), c_int(0)
+        _chk(self.L.papof_sor_plan(self.h, h, w, n_sor, mode, ctypes.byref(nl), ctypes.byref(d)), "papof_sor_plan")
+        return nl.value, d.value
 
     def bench_sor(self, h, w, n_sor, mode=SOR_EXACT, reps=5, seed=2):
         ms = c_double(0)

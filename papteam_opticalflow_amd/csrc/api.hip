@@ -1393,6 +1393,10 @@ int papof_flow_to_bgr(papof_handle* h, const double* vx, const double* vy, int h
     return PAPOF_OK;
 }
 
+int papof_sor_plan(papof_handle* h, int height, int width, int n_sor, int sor_mode, int* launches, int* depth) {
+    return sor_plan(h, height, width, n_sor, sor_mode, launches, depth);
+}
+
 // SOR micro-benchmark on synthetic planes resident in HBM: phi~U(0.5,50), imdx2/imdy2~U(0,.05),
 // imdxy~U(-.02,.02), rhs~U(-.01,.01); alpha .012, omega 1.8.
 int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_mode, int reps, unsigned seed,

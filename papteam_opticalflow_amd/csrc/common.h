@@ -317,6 +317,7 @@ int sor_redblack_halfsweep(papof_handle* h, const SorPlanes& sp, int H, int W, d
 int sor_blocked_depth(const papof_handle* h, int mode, int H, int W);  // half-sweeps per launch the blocked solver uses
 int sor_blocked_launch(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int mode, int g,
                        int hs0, const Rect& out, const double* su, const double* sv, double* du, double* dv);
+int sor_plan(const papof_handle* h, int H, int W, int n_sor, int mode, int* launches, int* depth);
 int sor_check(papof_handle* h);  // after a stream sync: PAPOF_ETIMEOUT if a device-side wait expired
 int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes& sp);  // carve the operand planes
 int sor_bind(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor);  // choose the layout of the next solves (skew mode)

@@ -1658,22 +1658,36 @@ int sor_blocked_launch(papof_handle* h, const SorPlanes& sp, int H, int W, doubl
 
 // `units` half-sweeps (Jacobi: sweeps) from zero on the whole plane: ceil(units / depth) launches of nearly equal depth,
 // alternating between the two pairs of planes so that the LAST one writes (sp.du, sp.dv).
+int sor_group_size(const papof_handle* h, int H, int W, int n_sor);
+static int sor_fuse_size(const papof_handle* h, int H, int W, int n_sor, int group);
+
+struct BlockedPlan {
+    int q, n_launch, base, rem;  // launch l runs q * (base + (l < rem)) half-sweeps (Jacobi: sweeps)
+};
+static BlockedPlan blocked_plan(const papof_handle* h, int mode, int H, int W, int units) {
+    const BlockedShape bs = blocked_shape(h, mode, H, W);
+    const bool one_block = W <= 2 * kLanes && H <= bs.nw * bs.rpt;
+    BlockedPlan p;
+    // Red-black: launches hold whole sweeps (an even number of half-sweeps) whenever the depth allows
+    p.q = (mode == PAPOF_SOR_REDBLACK && units % 2 == 0) ? 2 : 1;  // half-sweeps per planning unit
+    const int n_units = units / p.q;
+    const int depth = one_block ? n_units : std::max(1, sor_blocked_depth(h, mode, H, W) / p.q);
+    p.n_launch = (n_units + depth - 1) / depth;
+    p.base = n_units / p.n_launch;
+    p.rem = n_units % p.n_launch;
+    return p;
+}
+
 static int sor_blocked_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int mode,
                              int units) {
     if (!sp.du2 || !sp.dv2) return PAPOF_EINVAL;
-    const BlockedShape bs = blocked_shape(h, mode, H, W);
-    const bool one_block = W <= 2 * kLanes && H <= bs.nw * bs.rpt;
-    // Red-black: launches hold whole sweeps (an even number of half-sweeps) whenever the depth allows
-    const int q = (mode == PAPOF_SOR_REDBLACK && units % 2 == 0) ? 2 : 1;  // half-sweeps per planning unit
-    const int n_units = units / q;
-    const int depth = one_block ? n_units : std::max(1, sor_blocked_depth(h, mode, H, W) / q);
-    const int n_launch = (n_units + depth - 1) / depth, base = n_units / n_launch, rem = n_units % n_launch;
+    const BlockedPlan bp = blocked_plan(h, mode, H, W, units);
     const Rect all{0, 0, W, H};
     const double *su = nullptr, *sv = nullptr;
-    bool to_main = (n_launch & 1) != 0;  // odd count: start in the main pair, so that the last launch ends there too
+    bool to_main = (bp.n_launch & 1) != 0;  // odd count: start in the main pair, so that the last launch ends there too
     int done = 0;
-    for (int l = 0; l < n_launch; l++) {
-        const int g = q * (base + (l < rem ? 1 : 0));
+    for (int l = 0; l < bp.n_launch; l++) {
+        const int g = bp.q * (bp.base + (l < bp.rem ? 1 : 0));
         double *du = to_main ? sp.du : sp.du2, *dv = to_main ? sp.dv : sp.dv2;
         PAPOF_TRY(sor_blocked_launch(h, sp, H, W, alpha, omega, mode, g, done, all, su, sv, du, dv));
         su = du;
@@ -1681,6 +1695,37 @@ static int sor_blocked_solve(papof_handle* h, const SorPlanes& sp, int H, int W,
         done += g;
         to_main = !to_main;
     }
+    return PAPOF_OK;
+}
+
+// How sor_solve() runs a solve (measurement aid, papof_sor_plan): solver kernel launches per solve and, for the blocked
+// solver, the largest number of half-sweeps (Jacobi: sweeps) one launch runs.
+int sor_plan(const papof_handle* h, int H, int W, int n_sor, int mode, int* launches, int* depth) {
+    if (!h || H < 1 || W < 1 || n_sor < 1) return PAPOF_EINVAL;
+    int nl = 0, d = 0;
+    if (mode == PAPOF_SOR_EXACT) {
+        const int group = sor_group_size(h, H, W, n_sor);
+        const SkewDims sd = skew_dims(H, W, n_sor, group, sor_fuse_size(h, H, W, n_sor, group));
+        const bool aff = h->sor_xcd_affine && (sd.nb <= 8 || (h->sor_xcd_affine > 1 && sd.group == 1));
+        const int per = aff ? 8 * ((sd.nb + 7) / 8) : sd.nb;
+        const int units = sd.group > 1 ? (n_sor + sd.group - 1) / sd.group : (sd.fuse == 2 ? (n_sor + 1) / 2 : n_sor);
+        const int chunk = std::max(1, resident_tasks(h) / (per * std::max(1, sd.group)));
+        nl = (units + chunk - 1) / chunk;
+        d = sd.fuse == 2 ? 2 : sd.group;
+    } else if (mode == PAPOF_SOR_REDBLACK || mode == PAPOF_SOR_JACOBI) {
+        if (h->rb_naive) {
+            nl = mode == PAPOF_SOR_REDBLACK ? 2 * n_sor : n_sor;
+            d = 1;
+        } else {
+            const BlockedPlan bp = blocked_plan(h, mode, H, W, mode == PAPOF_SOR_REDBLACK ? 2 * n_sor : n_sor);
+            nl = bp.n_launch;
+            d = bp.q * (bp.base + (bp.rem ? 1 : 0));
+        }
+    } else {
+        return PAPOF_EINVAL;
+    }
+    if (launches) *launches = nl;
+    if (depth) *depth = d;
     return PAPOF_OK;
 }
 

@@ -6,7 +6,7 @@ FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read,
 exactly for 16-byte-per-lane streaming stores.  Infinity-Cache hits are counted too (these are L2 fabric-side
 requests), so "traffic" is an upper bound of the HBM bytes.
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <key> [kernel substring]
+usage: pmc_traffic.py <fetch_counter_collection.csv | run_results.db> <write ... .csv | .db> <key> [kernel substring]
 """
 import csv
 import json
@@ -16,6 +16,10 @@ import sys
 
 def per_dispatch(path, counter, kernel):
     vals = []
+    if path.endswith(".db"):  # rocpd database (the default output of ROCm 7.2's rocprofv3)
+        import sqlite3
+        q = "select value from counters_collection where counter_name = ? and kernel_name like ?"
+        return [float(v[0]) for v in sqlite3.connect(path).execute(q, (counter, "%" + kernel + "%"))]
     for r in csv.DictReader(open(path)):
         if r.get("Counter_Name") == counter and kernel in r.get("Kernel_Name", ""):
             vals.append(float(r["Counter_Value"]))
