@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PAPOF_VERSION 100 /* 0.1.0 */
+#define PAPOF_VERSION 101 /* 0.1.1: papof_params gained interpolation / noise_model */
 
 enum {
     PAPOF_OK = 0,
@@ -47,6 +47,20 @@ enum {
     PAPOF_SOR_JACOBI = 2    /* every cell from the previous sweep: correctness-gate mode (config 2)   */
 };
 
+/* The reference's two non-default branches, selected there by file-scope statics that its Python entry point cannot
+ * reach (src/OpticalFlow.cpp:32-34). */
+enum {
+    PAPOF_INTERP_BILINEAR = 0, /* warpFL (the default, src/OpticalFlow.cpp:33)                                     */
+    PAPOF_INTERP_BICUBIC = 1   /* in-loop Image::warpImageBicubicRef (+ threshold) on the feature images, :517-521, :816 */
+};
+enum {
+    PAPOF_NOISE_LAPLACIAN = 0, /* psi = 1 / (2 sqrt(t^2 + eps)) (the default, :34, :399-402)                        */
+    PAPOF_NOISE_GMIXTURE = 1   /* two-component Gaussian mixture per channel (:359-367, :389-397), re-estimated by EM
+                                  after every outer iteration (estGaussianMixture, :539-591).  Uses exp() and global
+                                  sums: NOT bit-compatible with the reference (device exp <= 1 ulp, parallel sums);
+                                  checked within 1e-6 on (u, v) -- BASELINE's bar is 1e-4                             */
+};
+
 /* Solver parameters.  The reference hard-codes all of them (src/OpticalFlow.cpp:747-751, :451, :823);
  * papof_default_params() reproduces those values, so passing NULL == the reference. */
 typedef struct papof_params {
@@ -59,8 +73,15 @@ typedef struct papof_params {
     int n_sor_per_level;   /* 3      ... plus this many per pyramid level k     :823 (nCG+k*3)          */
     double omega;          /* 1.8    over-relaxation factor                     :451                    */
     int sor_mode;          /* PAPOF_SOR_*                                                                */
-    int phase_timing;      /* 0: only "Total C++ Execution" and "Phase5_SOR" are measured (HIP events around
-                              the call and around each SOR launch); 1: all ten reference timers             */
+    int phase_timing;      /* All ten reference timers are always measured (HIP events on the streams, no synchronisation).
+                              0: flow-independent work (pyramids = Construction, features = Allocation, derivative planes of
+                                 the final warp = PostProcessing) runs on a second stream BESIDE the solver phases, so the
+                                 ten values overlap in time and add up to more than the total;
+                              1: everything on one stream: phases do not overlap (slower by the lost overlap).
+                              Phase5_SOR is the solver kernels' own duration in both cases.  Phase3_PsiData and
+                              Phase4_LinearSystem are ONE fused kernel here: its time is apportioned 30 : 70.          */
+    int interpolation;     /* PAPOF_INTERP_*  (0 = the reference's default)                                          */
+    int noise_model;       /* PAPOF_NOISE_*   (0 = the reference's default)                                          */
 } papof_params;
 
 /* Index of each reference timer in timing_sec[] == sorted std::map key order, src/OpticalFlow.cpp:850-860 */
@@ -227,6 +248,21 @@ int papof_stage_sor(papof_handle* h, const double* phi, const double* imdxy, con
 int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2, double* warp, double* u,
                            double* v, int height, int width, int c, double alpha, int n_outer, int n_inner,
                            int n_sor, double omega, int sor_mode);
+/* GaussianPyramid::ConstructPyramid (the min-width variant the reference does not call, src/GaussianPyramid.cpp:47-77)
+ * differs from ConstructPyramidLevels in its level count only: *levels = (int)(log((double)min_width / width) /
+ * log(ratio)) after the same clamp of the ratio (:50-53); pass it as `levels` / `pyramid_levels` anywhere. */
+int papof_pyramid_levels_for_min_width(int width, double ratio, int min_width, int* levels);
+/* SmoothFlowSOR with the non-default branches: interpolation / noise_model as in papof_params; gm (5 * c doubles: alpha,
+ * sigma, beta, sigma^2, beta^2 per channel; NULL = GaussianMixture::reset() values) is in/out when noise_model = GMIXTURE. */
+int papof_stage_smoothflow_ex(papof_handle* h, const double* im1, const double* im2, double* warp, double* u,
+                              double* v, int height, int width, int c, double alpha, int n_outer, int n_inner,
+                              int n_sor, double omega, int sor_mode, int interpolation, int noise_model, double* gm);
+/* OpticalFlow::estGaussianMixture, src/OpticalFlow.cpp:539-591 (prior 0.9); gm in/out as above. */
+int papof_stage_est_gaussian_mixture(papof_handle* h, const double* im1, const double* im2, int height, int width,
+                                     int c, double* gm);
+/* Image::warpImageBicubicRef alone (clamp = 0: the first warp of a level, src/OpticalFlow.cpp:816) or with threshold(). */
+int papof_stage_bicubic_warp_ex(papof_handle* h, const double* im1, const double* im2, const double* vx,
+                                const double* vy, int height, int width, int c, int clamp, double* out);
 /* Image::warpImageBicubicRef + threshold, src/Image.h:2587-2701, :2031-2045 (final warp of the originals). */
 int papof_stage_bicubic_warp(papof_handle* h, const double* im1, const double* im2, const double* vx,
                              const double* vy, int height, int width, int c, double* out);

@@ -44,6 +44,8 @@ void orc_default_params(orc_params* p) {
     p->n_sor_per_level = 3;
     p->omega = 1.8; /* :451 */
     p->sor_mode = ORC_SOR_EXACT;
+    p->interpolation = ORC_INTERP_BILINEAR; /* :33 */
+    p->noise_model = ORC_NOISE_LAP;         /* :34 */
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -148,6 +150,15 @@ void orc_resize_wh(const double* src, double* dst, int sw, int sh, int c, int dw
 /* ---------------------------------------------------------------------------------------------
  * GaussianPyramid::ConstructPyramidLevels, src/GaussianPyramid.cpp:79-108.
  * ------------------------------------------------------------------------------------------- */
+/* GaussianPyramid::ConstructPyramid (src/GaussianPyramid.cpp:47-77) differs from ConstructPyramidLevels (:79-108) in
+ * ONE line: the level count comes from a minimum width, nLevels = log((double)minWidth / width) / log(ratio) (:53,
+ * double -> int truncation), after the same clamp of the ratio (:50-51).  Everything else is orc_pyramid(). */
+int orc_pyramid_levels_for_min_width(int width, double ratio, int min_width) {
+    if (ratio > 0.98 || ratio < 0.4) ratio = 0.75;
+    const int n = log((double)min_width / width) / log(ratio);
+    return n;
+}
+
 long orc_pyramid(const double* im, int h, int w, int c, double ratio, int levels, int* dims, double* data) {
     if (ratio > 0.98 || ratio < 0.4) ratio = 0.75; /* :82-83 */
     const double base_sigma = 1 / ratio - 1;       /* :89 */
@@ -333,10 +344,53 @@ void orc_laplacian(const double* in, const double* weight, int h, int w, double*
  *   (src/Image.h:1537-1545), weighted Laplacian of u and v, right-hand sides (:444-448).
  * NOTE the reference differentiates uu=u+du for phi but applies Laplacian to u (:437-438).
  * ------------------------------------------------------------------------------------------- */
+/* GaussianMixture::Gaussian, src/NoiseModel.h:120-126.  gm = alpha[c], sigma[c], beta[c], sigma_square[c],
+ * beta_square[c] concatenated.  QUIRK: NoiseModel.h defines PI only `#ifndef PI` (:10-12), and in OpticalFlow.cpp it is
+ * reached through OpticalFlow.h:6-7 AFTER Image.h -> Stochastic.h:19 `#define PI 3.1415927`: the mixture densities are
+ * normalised with that 8-digit value (it cancels in the weights up to rounding -- which is what the golden vectors pin). */
+#define ORC_PI 3.1415927
+static inline double gm_gaussian(const double* gm, int c, double x, int i, int k) {
+    const double *sigma = gm + c, *beta = gm + 2 * c, *sigma2 = gm + 3 * c, *beta2 = gm + 4 * c;
+    if (i == 0) return exp(-x / (2 * sigma2[k])) / (2 * ORC_PI * sigma[k]);
+    return exp(-x / (2 * beta2[k])) / (2 * ORC_PI * beta[k]);
+}
+/* GaussianMixture::reset, src/NoiseModel.h:97-107 (+ square(), :131-138) */
+void orc_gm_reset(double* gm, int c) {
+    for (int k = 0; k < c; k++) {
+        gm[k] = 0.95;
+        gm[c + k] = 0.05;
+        gm[2 * c + k] = 0.5;
+        gm[3 * c + k] = gm[c + k] * gm[c + k];
+        gm[4 * c + k] = gm[2 * c + k] * gm[2 * c + k];
+    }
+}
+
+static void linear_system_impl(const double* imdx, const double* imdy, const double* imdt, const double* u,
+                               const double* v, const double* du, const double* dv, int h, int w, int c,
+                               double alpha, const double* lappara, const double* gm, double* phi, double* imdxy,
+                               double* imdx2, double* imdy2, double* imdtdx, double* imdtdy);
+
 void orc_linear_system(const double* imdx, const double* imdy, const double* imdt, const double* u,
                        const double* v, const double* du, const double* dv, int h, int w, int c, double alpha,
                        const double* lappara, double* phi, double* imdxy, double* imdx2, double* imdy2,
                        double* imdtdx, double* imdtdy) {
+    linear_system_impl(imdx, imdy, imdt, u, v, du, dv, h, w, c, alpha, lappara, NULL, phi, imdxy, imdx2, imdy2, imdtdx,
+                       imdtdy);
+}
+
+/* gm != NULL: the Gaussian-mixture noise model (noiseModel == GMixture, src/OpticalFlow.cpp:359-367 / :389-397) */
+void orc_linear_system_gm(const double* imdx, const double* imdy, const double* imdt, const double* u,
+                          const double* v, const double* du, const double* dv, int h, int w, int c, double alpha,
+                          const double* gm, double* phi, double* imdxy, double* imdx2, double* imdy2,
+                          double* imdtdx, double* imdtdy) {
+    linear_system_impl(imdx, imdy, imdt, u, v, du, dv, h, w, c, alpha, NULL, gm, phi, imdxy, imdx2, imdy2, imdtdx,
+                       imdtdy);
+}
+
+static void linear_system_impl(const double* imdx, const double* imdy, const double* imdt, const double* u,
+                               const double* v, const double* du, const double* dv, int h, int w, int c,
+                               double alpha, const double* lappara, const double* gm, double* phi, double* imdxy,
+                               double* imdx2, double* imdy2, double* imdtdx, double* imdtdy) {
     const size_t np = (size_t)w * h;
     const double eps_phi = 0.001 * 0.001, eps_psi = 0.001 * 0.001; /* pow(0.001,2), :261-262 */
     double* uu = zalloc(np);
@@ -365,7 +419,14 @@ void orc_linear_system(const double* imdx, const double* imdy, const double* imd
             double t = imdt[e] + imdx[e] * duo + imdy[e] * dvo;
             t *= t;
             double psi = 0.0;
-            if (!(lappara[k] < 1E-20)) psi = 1 / (2 * sqrt(t + eps_psi));
+            if (gm) { /* :392-396 */
+                const double prob1 = gm_gaussian(gm, c, t, 0, k) * gm[k];
+                const double prob2 = gm_gaussian(gm, c, t, 1, k) * (1 - gm[k]);
+                const double prob11 = prob1 / (2 * gm[3 * c + k]);
+                const double prob22 = prob2 / (2 * gm[4 * c + k]);
+                psi = (prob11 + prob22) / (prob1 + prob2);
+            } else if (!(lappara[k] < 1E-20))
+                psi = 1 / (2 * sqrt(t + eps_psi));
             if (c == 1) { /* :428-435: no collapse, plain copies */
                 sxy = psi * imdx[e] * imdy[e];
                 sx2 = psi * imdx[e] * imdx[e];
@@ -506,6 +567,58 @@ static void est_laplacian_noise(const double* im1, const double* im2, size_t np,
     free(total);
 }
 
+/* OpticalFlow::estGaussianMixture, src/OpticalFlow.cpp:539-591 (prior = 0.9, src/OpticalFlow.h:43): three EM iterations.
+ * Quirk kept: the M step calls para.reset() (:564) and then ACCUMULATES onto the reset values sigma = 0.05, beta = 0.5
+ * (:573-574) before dividing by the totals. */
+void orc_est_gaussian_mixture(const double* im1, const double* im2, long np, int c, double* gm, double prior) {
+    const size_t n = (size_t)np * c;
+    double* w1 = zalloc(n);
+    double* w2 = zalloc(n);
+    double* total1 = zalloc((size_t)c);
+    double* total2 = zalloc((size_t)c);
+    for (int count = 0; count < 3; count++) {
+        for (int k = 0; k < c; k++) total1[k] = total2[k] = 0;
+        for (long i = 0; i < np; i++) /* E step */
+            for (int k = 0; k < c; k++) {
+                const size_t o = (size_t)i * c + k;
+                double t = im1[o] - im2[o];
+                t *= t;
+                w1[o] = gm_gaussian(gm, c, t, 0, k) * gm[k];
+                w2[o] = gm_gaussian(gm, c, t, 1, k) * (1 - gm[k]);
+                t = w1[o] + w2[o];
+                w1[o] /= t;
+                w2[o] /= t;
+                total1[k] += w1[o];
+                total2[k] += w2[o];
+            }
+        orc_gm_reset(gm, c); /* M step */
+        for (long i = 0; i < np; i++)
+            for (int k = 0; k < c; k++) {
+                const size_t o = (size_t)i * c + k;
+                double t = im1[o] - im2[o];
+                t *= t;
+                gm[c + k] += w1[o] * t;
+                gm[2 * c + k] += w2[o] * t;
+            }
+        for (int k = 0; k < c; k++) {
+            gm[k] = total1[k] / (total1[k] + total2[k]) * (1 - prior) + 0.95 * prior;
+            gm[c + k] = sqrt(gm[c + k] / total1[k]);
+            gm[2 * c + k] = sqrt(gm[2 * c + k] / total2[k]) * (1 - prior) + 0.3 * prior;
+        }
+        for (int k = 0; k < c; k++) {
+            gm[3 * c + k] = gm[c + k] * gm[c + k];
+            gm[4 * c + k] = gm[2 * c + k] * gm[2 * c + k];
+        }
+    }
+    free(w1);
+    free(w2);
+    free(total1);
+    free(total2);
+}
+
+static void bicubic_warp_impl(const double* im1, const double* im2, const double* vx, const double* vy, int h, int w,
+                              int c, double* out, int clamp);
+
 /* ---------------------------------------------------------------------------------------------
  * OpticalFlow::SmoothFlowSOR, src/OpticalFlow.cpp:238-536.
  * phase_sec (may be NULL): [0]=Phase1 getDxs, [1]=Phase2..4 linear system, [2]=Phase5 SOR, [3]=Phase6.
@@ -514,6 +627,16 @@ static void est_laplacian_noise(const double* im1, const double* im2, size_t np,
 void orc_smoothflow_sor(const double* im1, const double* im2, double* warp, double* u, double* v, int h, int w,
                         int c, double alpha, int n_outer, int n_inner, int n_sor, double omega, int mode,
                         double* lappara, double* phase_sec) {
+    orc_smoothflow_sor_ex(im1, im2, warp, u, v, h, w, c, alpha, n_outer, n_inner, n_sor, omega, mode, lappara, phase_sec,
+                          ORC_INTERP_BILINEAR, NULL);
+}
+
+/* interpolation: how frame 2 is re-warped after each outer iteration (:515-521; Bicubic = warpImageBicubicRef +
+ * threshold on the FEATURE images).  gm != NULL: Gaussian-mixture noise model (psi :359-367, estGaussianMixture :524-528);
+ * gm is in/out (5 * c doubles, see orc_gm_reset). */
+void orc_smoothflow_sor_ex(const double* im1, const double* im2, double* warp, double* u, double* v, int h, int w,
+                           int c, double alpha, int n_outer, int n_inner, int n_sor, double omega, int mode,
+                           double* lappara, double* phase_sec, int interpolation, double* gm) {
     const size_t np = (size_t)w * h, n = np * c;
     double* imdx = zalloc(n);
     double* imdy = zalloc(n);
@@ -535,8 +658,8 @@ void orc_smoothflow_sor(const double* im1, const double* im2, double* warp, doub
         memset(dv, 0, sizeof(double) * np);
         for (int hh = 0; hh < n_inner; hh++) {
             t0 = now_sec();
-            orc_linear_system(imdx, imdy, imdt, u, v, hh == 0 ? NULL : du, hh == 0 ? NULL : dv, h, w, c, alpha,
-                              lappara, phi, imdxy, imdx2, imdy2, imdtdx, imdtdy);
+            linear_system_impl(imdx, imdy, imdt, u, v, hh == 0 ? NULL : du, hh == 0 ? NULL : dv, h, w, c, alpha,
+                               lappara, gm, phi, imdxy, imdx2, imdy2, imdtdx, imdtdy);
             memset(du, 0, sizeof(double) * np); /* :452-453 */
             memset(dv, 0, sizeof(double) * np);
             t1 = now_sec();
@@ -549,8 +672,14 @@ void orc_smoothflow_sor(const double* im1, const double* im2, double* warp, doub
             u[o] += du[o];
             v[o] += dv[o];
         }
-        orc_warpFL(im1, im2, u, v, h, w, c, warp); /* :516 */
-        est_laplacian_noise(im1, warp, np, c, lappara); /* :530 */
+        if (interpolation == ORC_INTERP_BILINEAR)
+            orc_warpFL(im1, im2, u, v, h, w, c, warp); /* :516 */
+        else
+            bicubic_warp_impl(im1, im2, u, v, h, w, c, warp, 1); /* :519-520: warpImageBicubicRef + threshold */
+        if (gm)
+            orc_est_gaussian_mixture(im1, warp, (long)np, c, gm, 0.9); /* :527 */
+        else
+            est_laplacian_noise(im1, warp, np, c, lappara); /* :530 */
         if (phase_sec) phase_sec[3] += now_sec() - t0;
     }
     free(imdx);
@@ -574,6 +703,16 @@ void orc_smoothflow_sor(const double* im1, const double* im2, double* warp, doub
  * ------------------------------------------------------------------------------------------- */
 void orc_bicubic_warp(const double* im1, const double* im2, const double* vx, const double* vy, int h, int w,
                       int c, double* out) {
+    bicubic_warp_impl(im1, im2, vx, vy, h, w, c, out, 1);
+}
+/* warpImageBicubicRef alone, without threshold(): the first warp of a level with interpolation == Bicubic
+ * (src/OpticalFlow.cpp:816) */
+void orc_bicubic_warp_noclamp(const double* im1, const double* im2, const double* vx, const double* vy, int h, int w,
+                              int c, double* out) {
+    bicubic_warp_impl(im1, im2, vx, vy, h, w, c, out, 0);
+}
+static void bicubic_warp_impl(const double* im1, const double* im2, const double* vx, const double* vy, int h, int w,
+                              int c, double* out, int clamp) {
     const size_t n = (size_t)w * h * c;
     const double df[3] = {-0.5, 0, 0.5};
     double* gx = zalloc(n);
@@ -633,7 +772,7 @@ void orc_bicubic_warp(const double* im1, const double* im2, const double* vx, co
                 out[o * c + k] = r;
             }
         }
-    for (size_t e = 0; e < n; e++) { /* threshold(): __min(__max(x,0),1) */
+    for (size_t e = 0; clamp && e < n; e++) { /* threshold(): __min(__max(x,0),1) */
         double r = out[e];
         r = r < 0 ? 0.0 : r;
         r = r > 1 ? 1.0 : r;
@@ -699,6 +838,11 @@ int orc_coarse2fine_flow(const double* im1, const double* im2, int h, int w, int
     const int fc = orc_im2feature(NULL, 1, 1, c, NULL);
     double* lappara = zalloc((size_t)(c + 2 > fc ? c + 2 : fc));
     for (int i = 0; i < c + 2; i++) lappara[i] = 0.02; /* :773-775 */
+    double* gm = NULL;
+    if (P.noise_model == ORC_NOISE_GMIXTURE) { /* :769-771: GMPara.reset(Im1.nchannels() + 2) */
+        gm = zalloc((size_t)5 * (c + 2 > fc ? c + 2 : fc));
+        orc_gm_reset(gm, fc);
+    }
     tm[1] = now_sec() - t0;
 
     double *u = NULL, *v = NULL;
@@ -731,11 +875,15 @@ int orc_coarse2fine_flow(const double* im1, const double* im2, int h, int w, int
             free(v);
             u = nu;
             v = nv;
-            orc_warpFL(f1, f2, u, v, lh, lw, fc, warp);
+            if (P.interpolation == ORC_INTERP_BILINEAR)
+                orc_warpFL(f1, f2, u, v, lh, lw, fc, warp);
+            else
+                bicubic_warp_impl(f1, f2, u, v, lh, lw, fc, warp, 0); /* :816: no threshold here */
         }
         tm[0] += now_sec() - t0;
-        orc_smoothflow_sor(f1, f2, warp, u, v, lh, lw, fc, P.alpha, P.n_outer + k * P.n_outer_per_level,
-                           P.n_inner, P.n_sor + k * P.n_sor_per_level, P.omega, P.sor_mode, lappara, phase);
+        orc_smoothflow_sor_ex(f1, f2, warp, u, v, lh, lw, fc, P.alpha, P.n_outer + k * P.n_outer_per_level,
+                              P.n_inner, P.n_sor + k * P.n_sor_per_level, P.omega, P.sor_mode, lappara, phase,
+                              P.interpolation, gm);
         pw = lw;
         ph = lh;
         free(f1);
@@ -760,5 +908,6 @@ int orc_coarse2fine_flow(const double* im1, const double* im2, int h, int w, int
     free(dims);
     free(offs);
     free(lappara);
+    free(gm);
     return 0;
 }

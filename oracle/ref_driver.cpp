@@ -267,4 +267,123 @@ int ref_flow_load16(const char* path, int h, int w, double* vx, double* vy) {
     return 0;
 }
 
+
+
+// ---- non-default branches of the reference: selected through its public statics
+// OpticalFlow::interpolation / noiseModel / GMPara (src/OpticalFlow.h:20-26), always restored afterwards ----
+namespace {
+struct Branches {  // interpolation: 0 bilinear, 1 bicubic;  noise_model: 0 Laplacian (the default), 1 Gaussian mixture
+    OpticalFlow::InterpolationMethod i0;
+    OpticalFlow::NoiseModel n0;
+    Branches(int interpolation, int noise_model) : i0(OpticalFlow::interpolation), n0(OpticalFlow::noiseModel) {
+        OpticalFlow::interpolation = interpolation ? OpticalFlow::Bicubic : OpticalFlow::Bilinear;
+        OpticalFlow::noiseModel = noise_model ? OpticalFlow::GMixture : OpticalFlow::Lap;
+    }
+    ~Branches() {
+        OpticalFlow::interpolation = i0;
+        OpticalFlow::noiseModel = n0;
+    }
+};
+void gm_out(double* gm, int c) {  // alpha[c], sigma[c], beta[c], sigma_square[c], beta_square[c]
+    const GaussianMixture& G = OpticalFlow::GMPara;
+    for (int k = 0; k < c; k++) {
+        gm[k] = G.alpha[k];
+        gm[c + k] = G.sigma[k];
+        gm[2 * c + k] = G.beta[k];
+        gm[3 * c + k] = G.sigma_square[k];
+        gm[4 * c + k] = G.beta_square[k];
+    }
+}
+void gm_in(const double* gm, int c) {
+    OpticalFlow::GMPara.reset(c);
+    GaussianMixture& G = OpticalFlow::GMPara;
+    for (int k = 0; k < c; k++) {
+        G.alpha[k] = gm[k];
+        G.sigma[k] = gm[c + k];
+        G.beta[k] = gm[2 * c + k];
+    }
+    G.square();
+}
+}  // namespace
+
+// OpticalFlow::Coarse2FineFlow itself (src/OpticalFlow.cpp:735-903) with the two statics set.
+int ref_coarse2fine_flow_opts(const double* im1, const double* im2, int h, int w, int c, int levels,
+                              int interpolation, int noise_model, double* vx, double* vy, double* warpI2) {
+    Quiet q;
+    Branches b(interpolation, noise_model);
+    DImage I1, I2, VX, VY, W2;
+    load(I1, im1, h, w, c, true);
+    load(I2, im2, h, w, c, true);
+    std::map<std::string, std::string> t;
+    OpticalFlow::Coarse2FineFlow(&t, VX, VY, W2, I1, I2, levels);
+    store(vx, VX);
+    store(vy, VY);
+    store(warpI2, W2);
+    return 0;
+}
+
+// One SmoothFlowSOR call with the branches selected; gm (5 * c doubles) is in/out when noise_model == 1.
+int ref_smoothflow_sor_opts(const double* im1, const double* im2, double* warp, double* u, double* v, int h, int w,
+                            int c, double alpha, int n_outer, int n_inner, int n_sor, int interpolation,
+                            int noise_model, double* gm) {
+    Quiet q;
+    Branches b(interpolation, noise_model);
+    DImage I1, I2, W2, U, V;
+    load(I1, im1, h, w, c);
+    load(I2, im2, h, w, c);
+    load(W2, warp, h, w, c);
+    load(U, u, h, w, 1);
+    load(V, v, h, w, 1);
+    set_lappara(c);
+    if (noise_model && gm) gm_in(gm, c);
+    OpticalFlow::SmoothFlowSOR(I1, I2, W2, U, V, alpha, n_outer, n_inner, n_sor);
+    if (noise_model && gm) gm_out(gm, c);
+    store(warp, W2);
+    store(u, U);
+    store(v, V);
+    return 0;
+}
+
+// OpticalFlow::estGaussianMixture (src/OpticalFlow.cpp:539-591), prior = its default 0.9; gm in/out.
+int ref_est_gaussian_mixture(const double* im1, const double* im2, int h, int w, int c, double* gm) {
+    DImage I1, I2;
+    load(I1, im1, h, w, c);
+    load(I2, im2, h, w, c);
+    gm_in(gm, c);
+    OpticalFlow::estGaussianMixture(I1, I2, OpticalFlow::GMPara);
+    gm_out(gm, c);
+    return 0;
+}
+
+// GaussianPyramid::ConstructPyramid (the min-width variant, src/GaussianPyramid.cpp:47-77); returns the level count.
+// dims must hold 2 * 64 ints; call with data == NULL first.
+int ref_pyramid_minwidth(const double* im, int h, int w, int c, double ratio, int min_width, int* dims, double* data) {
+    DImage I;
+    load(I, im, h, w, c, true);
+    GaussianPyramid P;
+    P.ConstructPyramid(I, ratio, min_width);
+    size_t off = 0;
+    for (int i = 0; i < P.nlevels() && i < 64; i++) {
+        dims[2 * i] = P.Image(i).width();
+        dims[2 * i + 1] = P.Image(i).height();
+        size_t n = (size_t)P.Image(i).width() * P.Image(i).height() * c;
+        if (data) std::memcpy(data + off, P.Image(i).data(), n * sizeof(double));
+        off += n;
+    }
+    return P.nlevels();
+}
+
+// Image::warpImageBicubicRef WITHOUT threshold(): the first warp of a level when interpolation == Bicubic (:816).
+int ref_bicubic_warp_noclamp(const double* im1, const double* im2, const double* vx, const double* vy, int h, int w,
+                             int c, double* out) {
+    DImage I1, I2, VX, VY, O;
+    load(I1, im1, h, w, c);
+    load(I2, im2, h, w, c);
+    load(VX, vx, h, w, 1);
+    load(VY, vy, h, w, 1);
+    I2.warpImageBicubicRef(I1, O, VX, VY);
+    store(out, O);
+    return 0;
+}
+
 }  // extern "C"

@@ -24,7 +24,7 @@ class Params(ctypes.Structure):
     """struct papof_params (include/papof.h); defaults = the reference's hard-coded constants."""
     _fields_ = [("alpha", c_double), ("ratio", c_double), ("n_outer", c_int), ("n_outer_per_level", c_int),
                 ("n_inner", c_int), ("n_sor", c_int), ("n_sor_per_level", c_int), ("omega", c_double),
-                ("sor_mode", c_int), ("phase_timing", c_int)]
+                ("sor_mode", c_int), ("phase_timing", c_int), ("interpolation", c_int), ("noise_model", c_int)]
 
 
 class PapofError(RuntimeError):
@@ -48,6 +48,8 @@ SYMBOLS = [
     "papof_tiles_halo_message", "papof_tiles_unique_id", "papof_tiles_create", "papof_tiles_create_local",
     "papof_tiles_flow_device", "papof_tiles_stats", "papof_tiles_destroy", "papof_flow_quantize16",
     "papof_flow_dequantize16", "papof_flow_to_bgr", "papof_set_graph_mode", "papof_sor_plan",
+    "papof_pyramid_levels_for_min_width", "papof_stage_smoothflow_ex", "papof_stage_est_gaussian_mixture",
+    "papof_stage_bicubic_warp_ex",
 ]
 
 
@@ -126,6 +128,11 @@ def load():
                                          c_int, c_double, c_int]
     L.papof_stage_bicubic_warp.argtypes = [c_void_p, _D, _D, _D, _D, c_int, c_int, c_int, _D]
     L.papof_bench_sor.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, _D]
+    L.papof_stage_smoothflow_ex.argtypes = [c_void_p, _D, _D, _D, _D, _D, c_int, c_int, c_int, c_double, c_int, c_int,
+                                            c_int, c_double, c_int, c_int, c_int, _D]
+    L.papof_stage_est_gaussian_mixture.argtypes = [c_void_p, _D, _D, c_int, c_int, c_int, _D]
+    L.papof_stage_bicubic_warp_ex.argtypes = [c_void_p, _D, _D, _D, _D, c_int, c_int, c_int, c_int, _D]
+    L.papof_pyramid_levels_for_min_width.argtypes = [c_int, c_double, c_int, ctypes.POINTER(c_int)]
     L.papof_sor_plan.argtypes = [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     _lib = L
     return L
@@ -393,6 +400,48 @@ class Papof:
         _chk(self.L.papof_stage_smoothflow(self.h, _p(im1), _p(im2), _p(warp), _p(u), _p(v), h, w, c, alpha, n_outer,
                                            n_inner, n_sor, omega, mode), "papof_stage_smoothflow")
         return warp, u, v
+
+    # ---- the reference's non-default branches (include/papof.h: PAPOF_INTERP_*, PAPOF_NOISE_*, min-width pyramid) ----
+    def pyramid_minwidth(self, im, ratio, min_width):
+        """GaussianPyramid::ConstructPyramid(image, ratio, minWidth), src/GaussianPyramid.cpp:47-77"""
+        n = c_int(0)
+        _chk(self.L.papof_pyramid_levels_for_min_width(np.shape(im)[1], ratio, min_width, ctypes.byref(n)),
+             "papof_pyramid_levels_for_min_width")
+        return self.pyramid(im, ratio, n.value)
+
+    def coarse2fine_flow_opts(self, im1, im2, levels, interpolation, noise_model):
+        return self.coarse2fine_flow(im1, im2, levels, default_params(interpolation=interpolation,
+                                                                      noise_model=noise_model))[:3]
+
+    def smoothflow_sor_opts(self, im1, im2, warp, u, v, alpha, n_outer, n_inner, n_sor, interpolation, noise_model):
+        im1, im2 = _c(im1, 3), _c(im2, 3)
+        warp, u, v = _c(warp, 3).copy(), _c(u, 2).copy(), _c(v, 2).copy()
+        h, w, c = im1.shape
+        gm = np.concatenate([np.full(c, 0.95), np.full(c, 0.05), np.full(c, 0.5), np.full(c, 0.05) ** 2,
+                             np.full(c, 0.5) ** 2])
+        _chk(self.L.papof_stage_smoothflow_ex(self.h, _p(im1), _p(im2), _p(warp), _p(u), _p(v), h, w, c, alpha, n_outer,
+                                              n_inner, n_sor, 1.8, SOR_EXACT, interpolation, noise_model, _p(gm)),
+             "papof_stage_smoothflow_ex")
+        return warp, u, v, gm
+
+    def est_gaussian_mixture(self, im1, im2, gm=None):
+        im1, im2 = _c(im1, 3), _c(im2, 3)
+        h, w, c = im1.shape
+        if gm is None:
+            gm = np.concatenate([np.full(c, 0.95), np.full(c, 0.05), np.full(c, 0.5), np.full(c, 0.05) ** 2,
+                                 np.full(c, 0.5) ** 2])
+        gm = np.ascontiguousarray(gm, dtype=np.float64).copy()
+        _chk(self.L.papof_stage_est_gaussian_mixture(self.h, _p(im1), _p(im2), h, w, c, _p(gm)),
+             "papof_stage_est_gaussian_mixture")
+        return gm
+
+    def bicubic_warp_noclamp(self, im1, im2, vx, vy):
+        im1, im2, vx, vy = _c(im1, 3), _c(im2, 3), _c(vx, 2), _c(vy, 2)
+        h, w, c = im1.shape
+        out = np.zeros_like(im1)
+        _chk(self.L.papof_stage_bicubic_warp_ex(self.h, _p(im1), _p(im2), _p(vx), _p(vy), h, w, c, 0, _p(out)),
+             "papof_stage_bicubic_warp_ex")
+        return out
 
     def bicubic_warp(self, im1, im2, vx, vy):
         im1, im2, vx, vy = _c(im1, 3), _c(im2, 3), _c(vx, 2), _c(vy, 2)

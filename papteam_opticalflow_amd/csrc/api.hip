@@ -108,6 +108,7 @@ size_t arena_bytes_for(int H, int W, int C, int levels, int n_sor_max, double ra
     planes += (size_t)7 * fc;              // F1, F2, warp, F1 smoothed, h-pass temp, blend, imdt
     planes += 8;                           // u, v, resized u, v, phi + slack
     planes += (size_t)3 * C + C;           // bicubic derivative planes + interleaved output
+    planes += (size_t)3 * fc;              // in-loop bicubic warping: derivative planes of the frame-2 features
     size_t bytes = planes * np * sizeof(double);
     bytes += 3 * (sor_cells + 2 * kLanes) * 16 + (sor_cells_d + 2 * kLanes) * 16 + 10 * np * sizeof(double);  // SOR operands
     bytes += per_level + np * fc * sizeof(double);  // + the preparation stream's own filter temporary
@@ -144,6 +145,8 @@ int check_params(const papof_params& P, int levels) {
     if (P.n_outer + 0 < 1 || P.n_sor < 1 || P.n_outer_per_level < 0 || P.n_sor_per_level < 0) return PAPOF_EINVAL;
     if (P.sor_mode < PAPOF_SOR_EXACT || P.sor_mode > PAPOF_SOR_JACOBI) return PAPOF_EINVAL;
     if (!(P.alpha > 0) || !(P.omega > 0)) return PAPOF_EINVAL;
+    if (P.interpolation != PAPOF_INTERP_BILINEAR && P.interpolation != PAPOF_INTERP_BICUBIC) return PAPOF_EINVAL;
+    if (P.noise_model != PAPOF_NOISE_LAPLACIAN && P.noise_model != PAPOF_NOISE_GMIXTURE) return PAPOF_EINVAL;
     return PAPOF_OK;
 }
 
@@ -197,6 +200,11 @@ int build_pyramid(papof_handle* h, const std::vector<Level>& L, const std::vecto
 struct SolveBuffers {
     double *im1s, *tmp, *blend, *imdt, *phi;
     SorPlanes sp;
+    // the reference's non-default branches (unreachable from its Python entry point; papof_params::interpolation /
+    // noise_model): derivative planes of the frame-2 features for in-loop bicubic warping (src/OpticalFlow.cpp:517-521),
+    // and the Gaussian-mixture parameters + reduction scratch (:359-367, :539-591)
+    double *bgx = nullptr, *bgy = nullptr, *bgxy = nullptr;
+    double *gm = nullptr, *gm_scratch = nullptr;
 };
 
 int alloc_solve_buffers(Arena& A, int H, int W, int fc, int mode, int n_sor_cap, SolveBuffers& B) {
@@ -210,16 +218,52 @@ int alloc_solve_buffers(Arena& A, int H, int W, int fc, int mode, int n_sor_cap,
     return A.overflow ? PAPOF_ENOMEM : PAPOF_OK;
 }
 
+// buffers of the non-default branches; gm is (re)set to GaussianMixture::reset()'s values (src/NoiseModel.h:97-107)
+int alloc_branch_buffers(papof_handle* h, Arena& A, int H, int W, int fc, int interpolation, int noise_model,
+                         SolveBuffers& B) {
+    const size_t np = (size_t)H * W;
+    if (interpolation == PAPOF_INTERP_BICUBIC) {
+        B.bgx = A.f64(np * fc);
+        B.bgy = A.f64(np * fc);
+        B.bgxy = A.f64(np * fc);
+    }
+    if (noise_model == PAPOF_NOISE_GMIXTURE) {
+        B.gm = A.f64(5 * 8);
+        B.gm_scratch = A.f64((size_t)gm_scratch_doubles());
+        if (A.overflow || fc > 8) return fc > 8 ? PAPOF_EINVAL : PAPOF_ENOMEM;
+        double init[40];
+        for (int k = 0; k < fc; k++) {
+            init[k] = 0.95;
+            init[fc + k] = 0.05;
+            init[2 * fc + k] = 0.5;
+            init[3 * fc + k] = 0.05 * 0.05;
+            init[4 * fc + k] = 0.5 * 0.5;
+        }
+        PAPOF_HIP(hipMemcpyAsync(B.gm, init, sizeof(double) * 5 * fc, hipMemcpyHostToDevice, h->stream));
+        PAPOF_HIP(hipStreamSynchronize(h->stream));  // `init` is a stack array
+    }
+    return A.overflow ? PAPOF_ENOMEM : PAPOF_OK;
+}
+
+// derivative planes {-.5, 0, .5} of the frame-2 features of a level (Image::warpImageBicubicRef, src/Image.h:2587-2595)
+int bicubic_planes(papof_handle* h, const double* f2, int H, int W, int fc, SolveBuffers& B) {
+    const Taps c3 = central3_taps();
+    PAPOF_TRY(filter_h(h, f2, B.bgx, H, W, fc, c3));
+    PAPOF_TRY(filter_v(h, f2, B.bgy, H, W, fc, c3));
+    PAPOF_TRY(filter_v(h, B.bgx, B.bgxy, H, W, fc, c3));
+    return PAPOF_OK;
+}
+
 // OpticalFlow::SmoothFlowSOR (src/OpticalFlow.cpp:238-536) for one level, everything on the device.
 // genInImageMask (:278) and estLaplacianNoise (:530) do not influence the results (the mask
 // is never read; the noise estimate only feeds a `< 1e-20` guard) and are not executed.
 int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* warp, double* u, double* v, int H,
                 int W, int fc, double alpha, int n_outer, int n_inner, int n_sor, double omega, int mode,
-                SolveBuffers& B, PhaseClock& clk, PhaseClock& sorclk, const double* im1s_ready = nullptr) {
+                SolveBuffers& B, PhaseClock& clk, const double* im1s_ready = nullptr) {
     const Taps g = smooth5_taps();
-    clk.phase(PAPOF_T_PHASE1_GENERATE);
     const double* im1s = im1s_ready;  // smoothed frame 1: constant within the level (prepared ahead by flow_device)
     if (!im1s) {
+        clk.phase(PAPOF_T_PHASE1_GENERATE);
         PAPOF_TRY(filter_h(h, f1, B.tmp, H, W, fc, g));
         PAPOF_TRY(filter_v(h, B.tmp, B.im1s, H, W, fc, g));
         im1s = B.im1s;
@@ -233,21 +277,31 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
             const SorPlanes* prev = hh == 0 ? nullptr : &B.sp;
             clk.phase(PAPOF_T_PHASE2_DERIVATIVES);
             PAPOF_TRY(compute_phi(h, u, v, prev, B.phi, H, W));
-            clk.phase(PAPOF_T_PHASE4_LINEARSYSTEM);  // psi (Phase3) is fused into the assembly kernel
+            // psi (Phase3, src/OpticalFlow.cpp:377-406) and the linear system (Phase4, :414-448) are ONE kernel here: its
+            // time is recorded under Phase4 and apportioned between the two timers when they are collected (kPsiShare)
+            clk.phase(PAPOF_T_PHASE4_LINEARSYSTEM);
             PAPOF_TRY(assemble_system(h, B.blend, B.imdt, B.phi, u, v, H, W, fc, alpha, omega, B.sp, nullptr, nullptr,
-                                      prev));
-            clk.phase(PAPOF_T_PHASE5_SOR);
-            // always measured: the roofline of the dominant kernel is priced on the solver kernel's own duration -- the
-            // events are recorded by sor_solve() right around its kernel(s), behind the memset nodes that prepare a solve
-            h->sor_mark = [](void* c, int on) { static_cast<PhaseClock*>(c)->phase(on ? PAPOF_T_PHASE5_SOR : -1); };
-            h->sor_mark_ctx = &sorclk;
+                                      prev, nullptr, B.gm));
+            // Phase5_SOR is the solver kernels' own duration (the roofline of the dominant kernel is priced on it): the
+            // events are recorded by sor_solve() right around its kernel(s), BEHIND the memset nodes that prepare a solve,
+            // which therefore still count as Phase4
+            h->sor_mark = [](void* c, int on) {
+                static_cast<PhaseClock*>(c)->phase(on ? PAPOF_T_PHASE5_SOR : PAPOF_T_PHASE6_UPDATE);
+            };
+            h->sor_mark_ctx = &clk;
             const int rc_solve = sor_solve(h, B.sp, H, W, alpha, omega, n_sor, mode);
             h->sor_mark = nullptr;
             h->sor_mark_ctx = nullptr;
             PAPOF_TRY(rc_solve);
         }
-        clk.phase(PAPOF_T_PHASE6_UPDATE);
-        PAPOF_TRY(update_and_warp(h, B.sp, u, v, f1, f2, warp, H, W, fc));
+        // Phase6 (opened by the solver's end mark): u += du, v += dv and the re-warp of frame 2 (:513-521)
+        if (!B.bgx) {
+            PAPOF_TRY(update_and_warp(h, B.sp, u, v, f1, f2, warp, H, W, fc));
+        } else {  // interpolation == Bicubic: warpImageBicubicRef + threshold() on the feature planes
+            PAPOF_TRY(update_and_warp(h, B.sp, u, v, f1, f2, warp, H, W, fc, false));
+            PAPOF_TRY(bicubic_warp(h, f1, f2, B.bgx, B.bgy, B.bgxy, u, v, warp, H, W, fc, nullptr, true, true));
+        }
+        if (B.gm) PAPOF_TRY(est_gaussian_mixture(h, f1, warp, H, W, fc, B.gm, B.gm_scratch));  // :524-528
     }
     clk.phase(-1);
     return PAPOF_OK;
@@ -310,7 +364,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     // ---- hipGraph mode: eager on the first call with these arguments, captured on the second, replayed afterwards
     enum { kEager, kCapture, kReplay } gmode = kEager;
     GraphEntry* ge = nullptr;
-    if (h->use_graph && op != kSeqPrime && P.phase_timing == 0) {
+    if (h->use_graph && op != kSeqPrime && P.phase_timing == 0 && P.noise_model == PAPOF_NOISE_LAPLACIAN) {
         GraphKey key;
         std::memset(&key, 0, sizeof key);
         key.H = H;
@@ -384,12 +438,19 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         }
     }
     const bool in_capture = gmode == kCapture;
-    PhaseClock clk{h, P.phase_timing != 0 && !in_capture};
-    PhaseClock sorclk{h, P.phase_timing == 0 && !in_capture};
+    // All ten reference timers (src/OpticalFlow.cpp:850-860) are ALWAYS measured, with HIP events recorded on the streams
+    // (no synchronisation): `clk` on the main stream, `pclk` on the preparation stream.  With phase_timing == 0 the two
+    // streams overlap, so Construction / Allocation / PostProcessing (preparation stream) run beside the solver phases
+    // and the ten values add up to more than the total; phase_timing == 1 runs everything on one stream.
+    PhaseClock clk{h, !in_capture};
+    PhaseClock pclk{h, !in_capture};
     PhaseClock total{h, !in_capture};
+    clk.only_sor = pclk.only_sor = !h->phase_events && P.phase_timing == 0;
+    clk.stamps = true;  // the main stream's phase boundaries are in-kernel stamps, not events (flow_internal.h)
+    h->stamps_used = 0;
+    h->next_stamp = nullptr;
 
     total.phase(PAPOF_T_TOTAL);
-    clk.phase(PAPOF_T_CONSTRUCTION);
     for (int i = 0; i < levels; i++) {  // the two pyramid slots: always the first allocations, at fixed offsets
         double* slot[2];
         slot[0] = A.f64((size_t)L[i].w * L[i].h * C);
@@ -399,7 +460,17 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     }
     double* tmp_a = A.f64(np0 * C);
     double* tmp_b = A.f64(np0 * C);
-    if (A.overflow) return PAPOF_ENOMEM;
+    const auto abandon_capture = [&]() {  // an error return must not leave a stream capture open on this handle
+        if (!in_capture) return;
+        hipGraph_t graph = nullptr;
+        hipStreamEndCapture(h->stream, &graph);
+        if (graph) hipGraphDestroy(graph);
+        h->use_graph = false;
+    };
+    if (A.overflow) {
+        abandon_capture();
+        return PAPOF_ENOMEM;
+    }
     const auto keep = [&](int slot) {
         h->seq.valid = true;
         h->seq.h = H;
@@ -441,8 +512,21 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     double* u2 = A.f64(np0);
     double* v2 = A.f64(np0);
     SolveBuffers B;
-    PAPOF_TRY(alloc_solve_buffers(A, H, W, fc, P.sor_mode, n_sor_max, B));
-    if (A.overflow) return PAPOF_ENOMEM;
+    {
+        const int rc_alloc = alloc_solve_buffers(A, H, W, fc, P.sor_mode, n_sor_max, B);
+        if (rc_alloc != PAPOF_OK || A.overflow) {
+            abandon_capture();
+            return rc_alloc != PAPOF_OK ? rc_alloc : PAPOF_ENOMEM;
+        }
+    }
+
+    {
+        const int rc_br = alloc_branch_buffers(h, A, H, W, fc, P.interpolation, P.noise_model, B);
+        if (rc_br != PAPOF_OK) {
+            abandon_capture();
+            return rc_br;
+        }
+    }
 
     const bool overlap = h->overlap_prep && P.phase_timing == 0 && h->prep_stream != nullptr;
     hipStream_t const main_stream = h->stream, prep = overlap ? h->prep_stream : h->stream;
@@ -459,6 +543,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     };
     const auto prepare = [&]() -> int {
         StreamSwap on_prep(h, prep);
+        pclk.phase(PAPOF_T_CONSTRUCTION);  // src/OpticalFlow.cpp:757-758 (and the wrapper's copies, Coarse2FineFlowWrapper.cpp:23-28)
         if (op != kSeqNext) PAPOF_TRY(load_frame(h, fa, L[0].p1, H, W, C));
         PAPOF_TRY(load_frame(h, fb, L[0].p2, H, W, C));
         // pyramid levels coarsest first when every level is derived from level 0 (<= 5 levels at ratio 0.75,
@@ -482,17 +567,25 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         if (!from_level0)
             for (int i = 1; i < levels; i++) PAPOF_TRY(build_level(i));
         for (int k = levels - 1; k >= 0; k--) {
-            if (from_level0) PAPOF_TRY(build_level(k));
+            if (from_level0) {
+                pclk.phase(PAPOF_T_CONSTRUCTION);
+                PAPOF_TRY(build_level(k));
+            }
+            pclk.phase(PAPOF_T_ALLOCATION);  // im2feature is inside the reference's Allocation timer (:797-798)
             PAPOF_TRY(im2feature(h, L[k].p1, F1[k], L[k].h, L[k].w, C));
             PAPOF_TRY(im2feature(h, L[k].p2, F2[k], L[k].h, L[k].w, C));
+            pclk.phase(PAPOF_T_PHASE1_GENERATE);  // smoothing of frame 1: first half of getDxs (:84-90)
             PAPOF_TRY(filter_h(h, F1[k], prep_tmp, L[k].h, L[k].w, fc, g5));
             PAPOF_TRY(filter_v(h, prep_tmp, S1[k], L[k].h, L[k].w, fc, g5));
+            pclk.phase(-1);
             if (overlap) PAPOF_HIP(hipEventRecord(h->sync_events[k], prep));
         }
+        pclk.phase(PAPOF_T_POSTPROCESSING);  // derivative planes of the final bicubic warp (src/Image.h:2590-2594)
         const Taps c3 = central3_taps();
         PAPOF_TRY(filter_h(h, L[0].p2, gx, H, W, C, c3));
         PAPOF_TRY(filter_v(h, L[0].p2, gy, H, W, C, c3));
         PAPOF_TRY(filter_v(h, gx, gxy, H, W, C, c3));
+        pclk.phase(-1);
         if (overlap) PAPOF_HIP(hipEventRecord(h->sync_events[levels], prep));
         return PAPOF_OK;
     };
@@ -519,33 +612,40 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     int rc_main = PAPOF_OK;
     const auto solve_levels = [&]() -> int {
         for (int k = levels - 1; k >= 0; k--) {
-            clk.phase(PAPOF_T_ALLOCATION);
             const int lw = L[k].w, lh = L[k].h;
             const size_t np = (size_t)lw * lh;
+            clk.phase(-1);  // waiting for the preparation stream is nobody's phase
             if (overlap) PAPOF_HIP(hipStreamWaitEvent(main_stream, h->sync_events[k], 0));
+            clk.phase(PAPOF_T_ALLOCATION);  // flow up-sampling and first warp of the level (:801-814)
             const double *f1 = F1[k], *f2 = F2[k];
             if (k == levels - 1) {  // src/OpticalFlow.cpp:801-806
                 PAPOF_HIP(hipMemsetAsync(u, 0, np * sizeof(double), h->stream));
                 PAPOF_HIP(hipMemsetAsync(v, 0, np * sizeof(double), h->stream));
                 PAPOF_HIP(hipMemcpyAsync(warp, f2, np * fc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-            } else {  // :809-814
+                if (B.bgx) PAPOF_TRY(bicubic_planes(h, f2, lh, lw, fc, B));
+            } else {  // :809-816
                 const double xr = (double)lw / pw, yr = (double)lh / ph, inv = 1 / ratio;
                 PAPOF_TRY(resize(h, u, u2, ph, pw, 1, lh, lw, xr, yr, true, inv));
                 PAPOF_TRY(resize(h, v, v2, ph, pw, 1, lh, lw, xr, yr, true, inv));
                 std::swap(u, u2);
                 std::swap(v, v2);
-                PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc));
+                if (!B.bgx) {
+                    PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc));
+                } else {  // interpolation == Bicubic (:816): warpImageBicubicRef, no threshold here
+                    PAPOF_TRY(bicubic_planes(h, f2, lh, lw, fc, B));
+                    PAPOF_TRY(bicubic_warp(h, f1, f2, B.bgx, B.bgy, B.bgxy, u, v, warp, lh, lw, fc, nullptr, true, false));
+                }
             }
             PAPOF_TRY(sor_bind(h, B.sp, lh, lw, P.n_sor + k * P.n_sor_per_level));
             PAPOF_TRY(sor_reset_planes(h, B.sp));
             PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, lh, lw, fc, P.alpha, P.n_outer + k * P.n_outer_per_level,
-                                  P.n_inner, P.n_sor + k * P.n_sor_per_level, P.omega, P.sor_mode, B, clk, sorclk,
-                                  S1[k]));
+                                  P.n_inner, P.n_sor + k * P.n_sor_per_level, P.omega, P.sor_mode, B, clk, S1[k]));
             pw = lw;
             ph = lh;
         }
-        clk.phase(PAPOF_T_POSTPROCESSING);  // src/OpticalFlow.cpp:841-842
+        clk.phase(-1);
         if (overlap) PAPOF_HIP(hipStreamWaitEvent(main_stream, h->sync_events[levels], 0));
+        clk.phase(PAPOF_T_POSTPROCESSING);  // src/OpticalFlow.cpp:841-842
         PAPOF_TRY(bicubic_warp(h, L[0].p1, L[0].p2, gx, gy, gxy, u, v, d_warp, H, W, C));
         PAPOF_HIP(hipMemcpyAsync(d_vx, u, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         PAPOF_HIP(hipMemcpyAsync(d_vy, v, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -572,13 +672,29 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         return rc_main;
     }
     clk.phase(-1);
+    PAPOF_TRY(stamp_only(h));  // the closing stamp of the last phase
     total.phase(-1);
+    h->stamps_fetched = 0;
+    if (h->stamps_dev && h->stamps_used > 0) {  // behind the total's end event: not part of any timer
+        PAPOF_HIP(hipMemcpyAsync(h->stamps, h->stamps_dev, (size_t)h->stamps_used * sizeof(unsigned long long),
+                                 hipMemcpyDeviceToHost, h->stream));
+        h->stamps_fetched = h->stamps_used;
+    }
     PAPOF_HIP(hipStreamSynchronize(h->stream));
+    h->next_stamp = nullptr;
     if (P.sor_mode == PAPOF_SOR_EXACT) PAPOF_TRY(sor_check(h));
-    if (clk.err != PAPOF_OK || total.err != PAPOF_OK) return PAPOF_EDEVICE;
+    if (clk.err != PAPOF_OK || pclk.err != PAPOF_OK || total.err != PAPOF_OK) return PAPOF_EDEVICE;
     clk.collect(tm);
-    sorclk.collect(tm);
+    pclk.collect(tm);
     total.collect(tm);
+    {   // the fused assembly kernel was recorded under Phase4: psi's share of it is Phase3_PsiData.  kPsiShare = the
+        // kernel's arithmetic that belongs to :377-406 (per channel: t*t, + eps, sqrt, 2*, 1/) over all of it, counted in
+        // the kernel's ISA (fp64 sqrt and division are ~25 instructions each); a fixed apportioning, not a measurement.
+        constexpr double kPsiShare = 0.3;
+        const double fused = tm[PAPOF_T_PHASE4_LINEARSYSTEM];
+        tm[PAPOF_T_PHASE3_PSIDATA] += kPsiShare * fused;
+        tm[PAPOF_T_PHASE4_LINEARSYSTEM] = fused - kPsiShare * fused;
+    }
     if (timing) std::memcpy(timing, tm, sizeof tm);
     if (op == kSeqNext) keep(slot1 ^ 1);  // the frame just solved against becomes frame 1 of the next push
     return PAPOF_OK;
@@ -607,6 +723,8 @@ void papof_default_params(papof_params* p) {
     p->omega = 1.8;
     p->sor_mode = PAPOF_SOR_EXACT;
     p->phase_timing = 0;
+    p->interpolation = PAPOF_INTERP_BILINEAR;
+    p->noise_model = PAPOF_NOISE_LAPLACIAN;
 }
 
 const char* papof_strerror(int code) {
@@ -674,6 +792,7 @@ int papof_create(int device, papof_handle** out) {
     }
     if (const char* cs = std::getenv("PAPOF_GRAPH")) h->use_graph = std::atoi(cs) != 0;
     if (const char* cs = std::getenv("PAPOF_OVERLAP")) h->overlap_prep = std::atoi(cs) != 0;
+    if (const char* cs = std::getenv("PAPOF_PHASE_EVENTS")) h->phase_events = std::atoi(cs) != 0;
     if (const char* cs = std::getenv("PAPOF_HOST_THREADS")) h->host_threads = std::max(1, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_SOR_DEPTH")) h->sor_depth = std::max(4, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_SOR_FUSE")) h->sor_fuse = std::max(1, std::atoi(cs));
@@ -687,6 +806,15 @@ int papof_create(int device, papof_handle** out) {
     if (rc != PAPOF_OK) {
         papof_destroy(h);
         return rc;
+    }
+    // slots for the phase stamps (device memory + a pinned host copy fetched once per call)
+    if (hipMalloc((void**)&h->stamps_dev, 4096 * sizeof(unsigned long long)) == hipSuccess &&
+        hipHostMalloc((void**)&h->stamps, 4096 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess) {
+        h->stamps_cap = 4096;
+    } else {  // no stamps: the stamped timers read 0, everything else works
+        if (h->stamps_dev) hipFree(h->stamps_dev);
+        h->stamps_dev = nullptr;
+        h->stamps = nullptr;
     }
     *out = h;
     return PAPOF_OK;
@@ -706,6 +834,8 @@ void papof_destroy(papof_handle* h) {
     if (h->sync_words) hipFree(h->sync_words);
     if (h->stage_dev) hipFree(h->stage_dev);
     if (h->pin) hipHostFree(h->pin);
+    if (h->stamps) hipHostFree(h->stamps);
+    if (h->stamps_dev) hipFree(h->stamps_dev);
     delete h->pool;
     hipStreamDestroy(h->stream);
     delete h;
@@ -1292,13 +1422,21 @@ int papof_stage_sor(papof_handle* h, const double* phi, const double* imdxy, con
 int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2, double* warp, double* u,
                            double* v, int height, int width, int c, double alpha, int n_outer, int n_inner,
                            int n_sor, double omega, int sor_mode) {
+    return papof_stage_smoothflow_ex(h, im1, im2, warp, u, v, height, width, c, alpha, n_outer, n_inner, n_sor, omega,
+                                     sor_mode, PAPOF_INTERP_BILINEAR, PAPOF_NOISE_LAPLACIAN, nullptr);
+}
+
+int papof_stage_smoothflow_ex(papof_handle* h, const double* im1, const double* im2, double* warp, double* u,
+                              double* v, int height, int width, int c, double alpha, int n_outer, int n_inner,
+                              int n_sor, double omega, int sor_mode, int interpolation, int noise_model, double* gm) {
     if (!h || !im1 || !im2 || !warp || !u || !v || height < 1 || width < 1 || c < 1 || n_outer < 1 || n_sor < 1 ||
         sor_mode < PAPOF_SOR_EXACT || sor_mode > PAPOF_SOR_JACOBI)
         return PAPOF_EINVAL;
     if (n_inner < 1) return PAPOF_EINVAL;
-    Scope S(h, img_bytes(height, width, c, 12) + img_bytes(height, width, 1, 8) +
+    if (interpolation < 0 || interpolation > 1 || noise_model < 0 || noise_model > 1) return PAPOF_EINVAL;
+    Scope S(h, img_bytes(height, width, c, 16) + img_bytes(height, width, 1, 8) +
                    sor_scratch_bytes(height, width, n_sor) +
-                   12 * (size_t)height * width * sizeof(double));
+                   12 * (size_t)height * width * sizeof(double) + (1 << 20));
     PAPOF_TRY(S.rc);
     double* f1 = S.up_planar(im1, height, width, c);
     double* f2 = S.up_planar(im2, height, width, c);
@@ -1308,20 +1446,56 @@ int papof_stage_smoothflow(papof_handle* h, const double* im1, const double* im2
     PAPOF_TRY(S.rc);
     SolveBuffers B;
     PAPOF_TRY(alloc_solve_buffers(h->arena, height, width, c, sor_mode, n_sor, B));
+    PAPOF_TRY(alloc_branch_buffers(h, h->arena, height, width, c, interpolation, noise_model, B));
+    if (B.gm && gm) PAPOF_HIP(hipMemcpyAsync(B.gm, gm, sizeof(double) * 5 * c, hipMemcpyHostToDevice, h->stream));
+    if (B.bgx) PAPOF_TRY(bicubic_planes(h, f2, height, width, c, B));
     PAPOF_TRY(sor_bind(h, B.sp, height, width, n_sor));
     PAPOF_TRY(sor_reset_planes(h, B.sp));
-    PhaseClock clk{h, false}, sorclk{h, false};
+    PhaseClock clk{h, false};
     PAPOF_TRY(smooth_flow(h, f1, f2, w, du, dv, height, width, c, alpha, n_outer, n_inner, n_sor, omega, sor_mode, B,
-                          clk, sorclk));
+                          clk));
     PAPOF_TRY(S.down_planar(w, warp, height, width, c));
     PAPOF_TRY(S.down_planar(du, u, height, width, 1));
     PAPOF_TRY(S.down_planar(dv, v, height, width, 1));
+    if (B.gm && gm) {
+        PAPOF_HIP(hipMemcpyAsync(gm, B.gm, sizeof(double) * 5 * c, hipMemcpyDeviceToHost, h->stream));
+        PAPOF_HIP(hipStreamSynchronize(h->stream));
+    }
     if (sor_mode == PAPOF_SOR_EXACT) PAPOF_TRY(sor_check(h));
+    return PAPOF_OK;
+}
+
+int papof_stage_est_gaussian_mixture(papof_handle* h, const double* im1, const double* im2, int height, int width,
+                                     int c, double* gm) {
+    if (!h || !im1 || !im2 || !gm || height < 1 || width < 1 || c < 1 || c > 8) return PAPOF_EINVAL;
+    Scope S(h, img_bytes(height, width, c, 6) + (1 << 20));
+    PAPOF_TRY(S.rc);
+    double* a = S.up_planar(im1, height, width, c);
+    double* b = S.up_planar(im2, height, width, c);
+    double* g = S.dev(40);
+    double* scratch = S.dev((size_t)gm_scratch_doubles());
+    PAPOF_TRY(S.rc);
+    PAPOF_HIP(hipMemcpyAsync(g, gm, sizeof(double) * 5 * c, hipMemcpyHostToDevice, h->stream));
+    PAPOF_TRY(est_gaussian_mixture(h, a, b, height, width, c, g, scratch));
+    PAPOF_HIP(hipMemcpyAsync(gm, g, sizeof(double) * 5 * c, hipMemcpyDeviceToHost, h->stream));
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    return PAPOF_OK;
+}
+
+int papof_pyramid_levels_for_min_width(int width, double ratio, int min_width, int* levels) {
+    if (width < 1 || min_width < 1 || !levels) return PAPOF_EINVAL;
+    if (ratio > 0.98 || ratio < 0.4) ratio = 0.75;  // src/GaussianPyramid.cpp:50-51
+    *levels = (int)(std::log((double)min_width / width) / std::log(ratio));  // :53
     return PAPOF_OK;
 }
 
 int papof_stage_bicubic_warp(papof_handle* h, const double* im1, const double* im2, const double* vx,
                              const double* vy, int height, int width, int c, double* out) {
+    return papof_stage_bicubic_warp_ex(h, im1, im2, vx, vy, height, width, c, 1, out);
+}
+
+int papof_stage_bicubic_warp_ex(papof_handle* h, const double* im1, const double* im2, const double* vx,
+                                const double* vy, int height, int width, int c, int clamp, double* out) {
     if (!h || !im1 || !im2 || !vx || !vy || !out || height < 1 || width < 1 || c < 1) return PAPOF_EINVAL;
     Scope S(h, img_bytes(height, width, c, 10) + img_bytes(height, width, 1, 4));
     PAPOF_TRY(S.rc);
@@ -1336,7 +1510,7 @@ int papof_stage_bicubic_warp(papof_handle* h, const double* im1, const double* i
     PAPOF_TRY(filter_h(h, b, gx, height, width, c, c3));
     PAPOF_TRY(filter_v(h, b, gy, height, width, c, c3));
     PAPOF_TRY(filter_v(h, gx, gxy, height, width, c, c3));
-    PAPOF_TRY(bicubic_warp(h, a, b, gx, gy, gxy, fx, fy, o, height, width, c));
+    PAPOF_TRY(bicubic_warp(h, a, b, gx, gy, gxy, fx, fy, o, height, width, c, nullptr, false, clamp != 0));
     PAPOF_HIP(hipMemcpyAsync(out, o, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     PAPOF_HIP(hipStreamSynchronize(h->stream));
     return PAPOF_OK;

@@ -257,6 +257,12 @@ struct papof_handle {
     hipStream_t prep_stream = nullptr;
     std::vector<hipEvent_t> sync_events;  // untimed events ordering the two streams
     bool overlap_prep = true;
+    // phase stamps (flow_internal.h: PhaseClock): slots the kernels write the 100 MHz clock into
+    unsigned long long* stamps_dev = nullptr;  // device slots
+    unsigned long long* stamps = nullptr;      // pinned host copy, fetched once per call
+    int stamps_cap = 0, stamps_used = 0, stamps_fetched = 0;
+    unsigned long long* next_stamp = nullptr;  // taken (and cleared) by the next kernel launch that supports stamps
+    bool phase_events = true;        // PAPOF_PHASE_EVENTS=0: record only the total and the solver kernels' events (A/B of the events' cost)
     int sor_xcd_affine = 1;          // 0: off; 1: when there are at most 8 bands; 2: always (see sor.hip)      // all sweeps of a band on one XCD (block index -> task mapping, speed only)
     // sequence mode (papof_seq_*): the pyramid of the last pushed frame stays in the arena and becomes "frame 1" of
     // the next pair.  Valid only while the arena block, the frame shape and the pyramid plan stay the same.
@@ -269,6 +275,13 @@ struct papof_handle {
 };
 
 namespace papof {
+
+inline unsigned long long* take_stamp(papof_handle* h) {
+    unsigned long long* s = h->next_stamp;
+    h->next_stamp = nullptr;
+    return s;
+}
+int stamp_only(papof_handle* h);  // kernels.hip
 
 // ---- kernels.hip: launch wrappers (all asynchronous on h->stream) ----
 int hwc_to_planar(papof_handle* h, const double* hwc, double* planar, int H, int W, int C);
@@ -291,13 +304,17 @@ int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlan
                 const Rect* rc = nullptr);
 int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,
                     const double* v, int H, int W, int planes, double alpha, double omega, const SorPlanes& out,
-                    double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev, const Rect* rc = nullptr);
+                    double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev, const Rect* rc = nullptr,
+                    const double* gm = nullptr);
+int gm_scratch_doubles();
+int est_gaussian_mixture(papof_handle* h, const double* im1, const double* im2, int H, int W, int C, double* gm,
+                         double* scratch);
 int laplacian(papof_handle* h, const double* in, const double* weight, double* out, int H, int W);
 int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, const double* im1,
-                    const double* im2, double* warp, int H, int W, int planes);
+                    const double* im2, double* warp, int H, int W, int planes, bool do_warp = true);
 int bicubic_warp(papof_handle* h, const double* im1, const double* im2, const double* gx, const double* gy,
                  const double* gxy, const double* vx, const double* vy, double* out_hwc, int H, int W, int C,
-                 const Rect* rc = nullptr);
+                 const Rect* rc = nullptr, bool planar_out = false, bool clamp = true);
 int flow_quantize16(papof_handle* h, const double* vx, const double* vy, unsigned short* q, size_t n);
 int flow_dequantize16(papof_handle* h, const unsigned short* q, double* vx, double* vy, size_t n);
 int flow_to_bgr(papof_handle* h, const double* vx, const double* vy, size_t n, double* partial, unsigned char* bgr);

@@ -20,6 +20,14 @@ inline dim3 grid2d(int W, int H, int planes = 1) { return dim3((W + BX - 1) / BX
 inline Rect region(const Rect* rc, int W, int H) { return rc ? *rc : Rect{0, 0, W, H}; }
 inline dim3 grid2d(const Rect& r, int planes = 1) { return grid2d(r.x1 - r.x0, r.y1 - r.y0, planes); }
 
+// Phase stamp: the first thread of a kernel's first block writes the constant 100 MHz clock where the host asked for
+// it (flow_internal.h: PhaseClock in stamp mode) -- the start of the first kernel of a phase IS the start of the phase,
+// at no cost to the stream (a HIP event between two kernels costs ~2.6 us of stream time; ~100 per call = 2 %).
+__device__ __forceinline__ void stamp_now(unsigned long long* s) {
+    if (s && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x | threadIdx.y) == 0u) *s = __builtin_amdgcn_s_memrealtime();
+}
+__global__ void k_stamp(unsigned long long* s) { stamp_now(s); }
+
 __device__ __forceinline__ int clampi(int x, int n) {  // EnforceRange, src/ImageProcessing.h:34
     x = x < 0 ? 0 : x;
     return x > n - 1 ? n - 1 : x;
@@ -116,7 +124,8 @@ __device__ __forceinline__ double bilinear_apply(const double* __restrict__ p, c
 // Optional post-scale = Image::Multiplywith (src/Image.h:1841-1850) for the flow up-sampling of
 // src/OpticalFlow.cpp:809-812.
 __global__ void k_resize(const double* __restrict__ src, double* __restrict__ dst, int sh, int sw, int dh, int dw,
-                         double xr, double yr, int use_post, double post, Rect rc) {
+                         double xr, double yr, int use_post, double post, Rect rc, unsigned long long* stamp) {
+    stamp_now(stamp);
     const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
     if (j >= rc.x1 || i >= rc.y1) return;
     const double x = (double)(j + 1) / xr - 1;
@@ -176,7 +185,9 @@ __device__ __forceinline__ void warp_pixel(const double* __restrict__ im1, const
 }
 
 __global__ void k_warp(const double* __restrict__ im1, const double* __restrict__ im2, const double* __restrict__ vx,
-                       const double* __restrict__ vy, double* __restrict__ out, int H, int W, int planes, Rect rc) {
+                       const double* __restrict__ vy, double* __restrict__ out, int H, int W, int planes, Rect rc,
+                       unsigned long long* stamp) {
+    stamp_now(stamp);
     const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
     if (j >= rc.x1 || i >= rc.y1) return;
     const size_t o = (size_t)i * W + j;
@@ -213,8 +224,9 @@ constexpr int kFuseRows = 16;
 __global__ __launch_bounds__(256) void k_smooth_hv_blend(const double* __restrict__ warp,
                                                          const double* __restrict__ im1s,
                                                          double* __restrict__ blend, double* __restrict__ imdt, int H,
-                                                         int W, Taps g) {
+                                                         int W, Taps g, unsigned long long* stamp) {
     __shared__ double hs[kFuseRows + 4][BX];
+    stamp_now(stamp);
     const int j = blockIdx.x * BX + threadIdx.x, i0 = blockIdx.y * kFuseRows;
     const size_t np = (size_t)H * W;
     const double* src = warp + blockIdx.z * np;
@@ -276,6 +288,8 @@ struct Increment {
     const double *du, *dv;
     int skew;
     SkewIdx sk;
+    const double* gm;  // Gaussian-mixture noise model (src/OpticalFlow.cpp:359-367): alpha[C], sigma[C], beta[C],
+                       // sigma_square[C], beta_square[C] of GaussianMixture (src/NoiseModel.h); null = Laplacian (default)
 };
 __device__ __forceinline__ void increment_at(const Increment& I, int i, int j, int W, double& du, double& dv) {
     if (I.du == nullptr) {
@@ -296,7 +310,8 @@ __device__ __forceinline__ void increment_at(const Increment& I, int i, int j, i
 // (zero in the last column / row, src/Image.h:979-986, :1022-1029), phi = 0.5/sqrt(ux^2+uy^2+vx^2+vy^2+eps).
 // ------------------------------------------------------------------------------------------------
 __global__ void k_phi(const double* __restrict__ u, const double* __restrict__ v, Increment I,
-                      double* __restrict__ phi, int H, int W, Rect rc) {
+                      double* __restrict__ phi, int H, int W, Rect rc, unsigned long long* stamp) {
+    stamp_now(stamp);
     const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
     if (j >= rc.x1 || i >= rc.y1) return;
     const size_t o = (size_t)i * W + j;
@@ -421,7 +436,21 @@ __device__ __forceinline__ SystemCell assemble_cell(const double* __restrict__ b
         double t = gt;  // imdt + imdx*du + imdy*dv (src/OpticalFlow.cpp:384); du = dv = 0 in the first inner iteration
         if (I.du != nullptr) t = gt + gx * du + gy * dv;
         t *= t;
-        const double psi = 1 / (2 * sqrt(t + 0.001 * 0.001));
+        double psi;
+        if (I.gm != nullptr) {  // :392-396 with GaussianMixture::Gaussian (src/NoiseModel.h:120-126).  The reference's PI there is
+                                // 3.1415927: Stochastic.h:19 defines it before NoiseModel.h's #ifndef (oracle/papof_oracle.c).
+                                // exp() is the device library's (<= 1 ulp, not glibc's bits): tolerance-checked branch.
+            const double* g = I.gm;
+            const double alpha_k = g[k], sigma = g[planes + k], beta = g[2 * planes + k];
+            const double s2 = g[3 * planes + k], b2 = g[4 * planes + k];
+            const double prob1 = exp(-t / (2 * s2)) / (2 * 3.1415927 * sigma) * alpha_k;
+            const double prob2 = exp(-t / (2 * b2)) / (2 * 3.1415927 * beta) * (1 - alpha_k);
+            const double prob11 = prob1 / (2 * s2);
+            const double prob22 = prob2 / (2 * b2);
+            psi = (prob11 + prob22) / (prob1 + prob2);
+        } else {
+            psi = 1 / (2 * sqrt(t + 0.001 * 0.001));
+        }
         const double pgx = psi * gx, pgy = psi * gy;
         if (planes == 1) {
             sxy = pgx * gy;
@@ -485,7 +514,9 @@ __global__ void k_assemble(const double* __restrict__ blend, const double* __res
                            const double* __restrict__ v, int H, int W, int planes, double alpha, double omega,
                            double* __restrict__ o_phi, double* __restrict__ o_xy, double* __restrict__ o_a1,
                            double* __restrict__ o_a2, double* __restrict__ o_b1, double* __restrict__ o_b2,
-                           double* __restrict__ o_x2, double* __restrict__ o_y2, Taps d, Increment I, Rect rc) {
+                           double* __restrict__ o_x2, double* __restrict__ o_y2, Taps d, Increment I, Rect rc,
+                           unsigned long long* stamp) {
+    stamp_now(stamp);
     const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
     if (j >= rc.x1 || i >= rc.y1) return;
     const size_t o = (size_t)i * W + j;
@@ -515,8 +546,10 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
                                                        double alpha, double omega, SkewIdx sk,
                                                        double2s* __restrict__ pa, double2s* __restrict__ pb,
                                                        double2s* __restrict__ pc, double* __restrict__ o_x2,
-                                                       double* __restrict__ o_y2, Taps d, Increment I) {
+                                                       double* __restrict__ o_y2, Taps d, Increment I,
+                                                       unsigned long long* stamp) {
     __shared__ double stage[6][kBandRows][kTileJ + 1];
+    stamp_now(stamp);
     const int b = blockIdx.y, j0 = blockIdx.x * kTileJ, tid = threadIdx.x;
     // block-uniform: no cell of this tile is closer than 2 pixels to an image border
     const bool interior = b * kBandRows >= 2 && b * kBandRows + kBandRows + 2 <= H && j0 >= 2 && j0 + kTileJ + 2 <= W;
@@ -598,7 +631,8 @@ __global__ void k_sor_unpack(const double* __restrict__ sdu, const double* __res
 __global__ void k_update_warp(const double* __restrict__ sdu, const double* __restrict__ sdv, double* __restrict__ u,
                               double* __restrict__ v, const double* __restrict__ im1,
                               const double* __restrict__ im2, double* __restrict__ warp, int H, int W, int planes, Rect rc,
-                              int do_warp) {
+                              int do_warp, unsigned long long* stamp) {
+    stamp_now(stamp);
     const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
     if (j >= rc.x1 || i >= rc.y1) return;
     const size_t o = (size_t)i * W + j;
@@ -614,7 +648,9 @@ __global__ void k_update_warp(const double* __restrict__ sdu, const double* __re
 // transposition of the tile was measured slower: the kernel is bound by the 4-tap x C-plane gather of the warp).
 __global__ void k_update_warp_skew(const double2s* __restrict__ pd, double* __restrict__ u, double* __restrict__ v,
                                    const double* __restrict__ im1, const double* __restrict__ im2,
-                                   double* __restrict__ warp, int H, int W, int planes, SkewIdx sk) {
+                                   double* __restrict__ warp, int H, int W, int planes, SkewIdx sk,
+                                   unsigned long long* stamp, int do_warp) {
+    stamp_now(stamp);
     const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
     if (j >= W || i >= H) return;
     const size_t o = (size_t)i * W + j;
@@ -624,7 +660,7 @@ __global__ void k_update_warp_skew(const double2s* __restrict__ pd, double* __re
     fv += c.y;
     u[o] = fu;
     v[o] = fv;
-    warp_pixel(im1, im2, warp, fu, fv, i, j, H, W, planes);
+    if (do_warp) warp_pixel(im1, im2, warp, fu, fv, i, j, H, W, planes);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -637,18 +673,25 @@ __global__ void k_update_warp_skew(const double2s* __restrict__ pd, double* __re
 __global__ void k_bicubic(const double* __restrict__ im1, const double* __restrict__ im2,
                           const double* __restrict__ gx, const double* __restrict__ gy,
                           const double* __restrict__ gxy, const double* __restrict__ vx,
-                          const double* __restrict__ vy, double* __restrict__ out, int H, int W, int C, Rect rc) {
+                          const double* __restrict__ vy, double* __restrict__ out, int H, int W, int C, Rect rc,
+                          unsigned long long* stamp, int planar_out, int clamp) {
+    // planar_out / clamp: the in-loop use on the feature planes (src/OpticalFlow.cpp:517-521 with threshold(), :816
+    // without); the final warp of the originals writes interleaved HWC and always clamps.
+    stamp_now(stamp);
     const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
     if (j >= rc.x1 || i >= rc.y1) return;
     const size_t np = (size_t)H * W, o = (size_t)i * W + j;
+    const size_t ostride = planar_out ? np : 1, obase = planar_out ? o : o * C;
     const double x = j + vx[o];
     const double y = i + vy[o];
     if (x < 0 || x > W - 1 || y < 0 || y > H - 1) {
         for (int k = 0; k < C; k++) {
             double r = im1[k * np + o];
-            r = r < 0 ? 0.0 : r;
-            r = r > 1 ? 1.0 : r;
-            out[o * C + k] = r;
+            if (clamp) {
+                r = r < 0 ? 0.0 : r;
+                r = r > 1 ? 1.0 : r;
+            }
+            out[obase + k * ostride] = r;
         }
         return;
     }
@@ -691,9 +734,11 @@ __global__ void k_bicubic(const double* __restrict__ im1, const double* __restri
         double r = c00 + c01 * dy + c02 * dy2 + c03 * dy3 + c10 * dx + c11 * dx * dy + c12 * dx * dy2 +
                    c13 * dx * dy3 + c20 * dx2 + c21 * dx2 * dy + c22 * dx2 * dy2 + c23 * dx2 * dy3 + c30 * dx3 +
                    c31 * dx3 * dy + c32 * dx3 * dy2 + c33 * dx3 * dy3;
-        r = r < 0 ? 0.0 : r;
-        r = r > 1 ? 1.0 : r;
-        out[o * C + k] = r;
+        if (clamp) {
+            r = r < 0 ? 0.0 : r;
+            r = r > 1 ? 1.0 : r;
+        }
+        out[obase + k * ostride] = r;
     }
 }
 
@@ -871,7 +916,7 @@ int resize(papof_handle* h, const double* src, double* dst, int sh, int sw, int 
     const Rect r = region(rc, dw, dh);
     if (r.empty()) return PAPOF_OK;
     hipLaunchKernelGGL(k_resize, grid2d(r, planes), dim3(BX, BY), 0, h->stream, src, dst, sh, sw, dh, dw, xr, yr,
-                       use_post ? 1 : 0, post, r);
+                       use_post ? 1 : 0, post, r, take_stamp(h));
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
@@ -893,7 +938,8 @@ int warp_bilinear(papof_handle* h, const double* im1, const double* im2, const d
                   double* out, int H, int W, int planes, const Rect* rc) {
     const Rect r = region(rc, W, H);
     if (r.empty()) return PAPOF_OK;
-    hipLaunchKernelGGL(k_warp, grid2d(r), dim3(BX, BY), 0, h->stream, im1, im2, vx, vy, out, H, W, planes, r);
+    hipLaunchKernelGGL(k_warp, grid2d(r), dim3(BX, BY), 0, h->stream, im1, im2, vx, vy, out, H, W, planes, r,
+                       take_stamp(h));
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
@@ -913,15 +959,16 @@ static SkewIdx skew_idx(const SorPlanes& sp) {
 }
 
 // `prev` = operands of the previous inner iteration's solve (nullptr in the first one: du = dv = 0)
-static Increment increment_of(const SorPlanes* prev) {
-    if (!prev) return Increment{nullptr, nullptr, 0, SkewIdx{0, 0, 0, 0, 0, 0, 0}};
-    return Increment{prev->du, prev->dv, prev->skew ? 1 : 0, prev->skew ? skew_idx(*prev) : SkewIdx{0, 0, 0, 0, 0, 0, 0}};
+static Increment increment_of(const SorPlanes* prev, const double* gm = nullptr) {
+    if (!prev) return Increment{nullptr, nullptr, 0, SkewIdx{0, 0, 0, 0, 0, 0, 0}, gm};
+    return Increment{prev->du, prev->dv, prev->skew ? 1 : 0, prev->skew ? skew_idx(*prev) : SkewIdx{0, 0, 0, 0, 0, 0, 0},
+                     gm};
 }
 
 int smooth_hv_blend(papof_handle* h, const double* warp, const double* im1s, double* blend, double* imdt, int H,
                     int W, int planes) {
     hipLaunchKernelGGL(k_smooth_hv_blend, dim3((W + BX - 1) / BX, (H + kFuseRows - 1) / kFuseRows, planes),
-                       dim3(BX, BY), 0, h->stream, warp, im1s, blend, imdt, H, W, smooth5_taps());
+                       dim3(BX, BY), 0, h->stream, warp, im1s, blend, imdt, H, W, smooth5_taps(), take_stamp(h));
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
@@ -930,15 +977,16 @@ int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlan
                 const Rect* rc) {
     const Rect r = region(rc, W, H);
     if (r.empty()) return PAPOF_OK;
-    hipLaunchKernelGGL(k_phi, grid2d(r), dim3(BX, BY), 0, h->stream, u, v, increment_of(prev), phi, H, W, r);
+    hipLaunchKernelGGL(k_phi, grid2d(r), dim3(BX, BY), 0, h->stream, u, v, increment_of(prev), phi, H, W, r,
+                       take_stamp(h));
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
 
 int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,
                     const double* v, int H, int W, int planes, double alpha, double omega, const SorPlanes& out,
-                    double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev, const Rect* rc) {
-    const Increment I = increment_of(prev);
+                    double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev, const Rect* rc, const double* gm) {
+    const Increment I = increment_of(prev, gm);
     const Rect r = region(rc, W, H);
     if (r.empty()) return PAPOF_OK;
     if (out.skew) {
@@ -946,11 +994,11 @@ int assemble_system(papof_handle* h, const double* blend, const double* imdt, co
         hipLaunchKernelGGL(k_assemble_skew, dim3((W + kTileJ - 1) / kTileJ, (H + kBandRows - 1) / kBandRows),
                            dim3(256), 0, h->stream, blend, imdt, phi, u, v, H, W, planes, alpha, omega, skew_idx(out),
                            (double2s*)out.phi, (double2s*)out.a1, (double2s*)out.b1, opt_imdx2, opt_imdy2,
-                           deriv5_taps(), I);
+                           deriv5_taps(), I, take_stamp(h));
     } else {
         hipLaunchKernelGGL(k_assemble, grid2d(r), dim3(BX, BY), 0, h->stream, blend, imdt, phi, u, v, H, W, planes,
                            alpha, omega, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2, opt_imdx2, opt_imdy2,
-                           deriv5_taps(), I, r);
+                           deriv5_taps(), I, r, take_stamp(h));
     }
     LAUNCH_CHECK();
     return PAPOF_OK;
@@ -963,13 +1011,13 @@ int laplacian(papof_handle* h, const double* in, const double* weight, double* o
 }
 
 int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, const double* im1,
-                    const double* im2, double* warp, int H, int W, int planes) {
+                    const double* im2, double* warp, int H, int W, int planes, bool do_warp) {
     if (sp.skew) {
         hipLaunchKernelGGL(k_update_warp_skew, grid2d(W, H), dim3(BX, BY), 0, h->stream, (const double2s*)sp.du, u, v,
-                           im1, im2, warp, H, W, planes, skew_idx(sp));
+                           im1, im2, warp, H, W, planes, skew_idx(sp), take_stamp(h), do_warp ? 1 : 0);
     } else {
         hipLaunchKernelGGL(k_update_warp, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, u, v, im1, im2, warp,
-                           H, W, planes, Rect{0, 0, W, H}, 1);
+                           H, W, planes, Rect{0, 0, W, H}, do_warp ? 1 : 0, take_stamp(h));
     }
     LAUNCH_CHECK();
     return PAPOF_OK;
@@ -980,7 +1028,7 @@ int update_flow(papof_handle* h, const SorPlanes& sp, double* u, double* v, int 
     if (sp.skew) return PAPOF_EINVAL;
     if (r.empty()) return PAPOF_OK;
     hipLaunchKernelGGL(k_update_warp, grid2d(r), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, u, v, nullptr, nullptr, nullptr,
-                       H, W, 0, r, 0);
+                       H, W, 0, r, 0, take_stamp(h));
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
@@ -1012,11 +1060,103 @@ int flow_to_bgr(papof_handle* h, const double* vx, const double* vy, size_t n, d
 
 int bicubic_warp(papof_handle* h, const double* im1, const double* im2, const double* gx, const double* gy,
                  const double* gxy, const double* vx, const double* vy, double* out_hwc, int H, int W, int C,
-                 const Rect* rc) {
+                 const Rect* rc, bool planar_out, bool clamp) {
     const Rect r = region(rc, W, H);
     if (r.empty()) return PAPOF_OK;
     hipLaunchKernelGGL(k_bicubic, grid2d(r), dim3(BX, BY), 0, h->stream, im1, im2, gx, gy, gxy, vx, vy, out_hwc, H, W,
-                       C, r);
+                       C, r, take_stamp(h), planar_out ? 1 : 0, clamp ? 1 : 0);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// OpticalFlow::estGaussianMixture, src/OpticalFlow.cpp:539-591 (prior 0.9): three EM iterations over all pixels and
+// channels.  One iteration = one reduction kernel (per channel: sum w1, sum w2, sum w1*d^2, sum w2*d^2 with the weights
+// of the CURRENT parameters, :551-575; the reference stores the weights, here they are recomputed -- same expressions)
+// + one single-block kernel that sums the per-block partials in a fixed order and applies the M step (:576-583, with
+// the reference's quirk of accumulating onto the reset values 0.05 / 0.5).  The reference sums sequentially over the
+// pixels; a parallel sum rounds differently in the last bits: this branch is checked with a tolerance.
+// Deterministic: fixed grid, fixed in-block tree, fixed order over the blocks.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGmBlocks = 256, kGmThreads = 256, kGmMaxC = 8;
+static __global__ __launch_bounds__(kGmThreads) void k_gm_partial(const double* __restrict__ im1,
+                                                           const double* __restrict__ im2, size_t np, int C,
+                                                           const double* __restrict__ gm, double* __restrict__ partial) {
+    __shared__ double red[kGmThreads];
+    double acc[kGmMaxC][4];
+    for (int k = 0; k < kGmMaxC; k++) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0;
+    for (size_t o = (size_t)blockIdx.x * kGmThreads + threadIdx.x; o < np; o += (size_t)kGmBlocks * kGmThreads) {
+#pragma unroll
+        for (int k = 0; k < kGmMaxC; k++) {
+            if (k >= C) break;
+            double t = im1[k * np + o] - im2[k * np + o];
+            t *= t;
+            const double alpha_k = gm[k], sigma = gm[C + k], beta = gm[2 * C + k], s2 = gm[3 * C + k], b2 = gm[4 * C + k];
+            double w1 = exp(-t / (2 * s2)) / (2 * 3.1415927 * sigma) * alpha_k;
+            double w2 = exp(-t / (2 * b2)) / (2 * 3.1415927 * beta) * (1 - alpha_k);
+            const double s = w1 + w2;
+            w1 /= s;
+            w2 /= s;
+            acc[k][0] += w1;
+            acc[k][1] += w2;
+            acc[k][2] += w1 * t;
+            acc[k][3] += w2 * t;
+        }
+    }
+    for (int k = 0; k < C; k++)
+        for (int q = 0; q < 4; q++) {
+            red[threadIdx.x] = acc[k][q];
+            __syncthreads();
+            for (int s = kGmThreads / 2; s > 0; s >>= 1) {
+                if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) partial[((size_t)blockIdx.x * kGmMaxC + k) * 4 + q] = red[0];
+            __syncthreads();
+        }
+}
+
+static __global__ void k_gm_mstep(const double* __restrict__ partial, int C, double prior, double* __restrict__ gm) {
+    const int k = threadIdx.x;
+    if (k >= C) return;
+    double t1 = 0.0, t2 = 0.0, s1 = 0.05, s2 = 0.5;  // para.reset() before the accumulation (:564, src/NoiseModel.h:97-107)
+    for (int b = 0; b < kGmBlocks; b++) {
+        const double* p = partial + ((size_t)b * kGmMaxC + k) * 4;
+        t1 += p[0];
+        t2 += p[1];
+        s1 += p[2];
+        s2 += p[3];
+    }
+    const double alpha = t1 / (t1 + t2) * (1 - prior) + 0.95 * prior;
+    const double sigma = sqrt(s1 / t1);
+    const double beta = sqrt(s2 / t2) * (1 - prior) + 0.3 * prior;
+    gm[k] = alpha;
+    gm[C + k] = sigma;
+    gm[2 * C + k] = beta;
+    gm[3 * C + k] = sigma * sigma;
+    gm[4 * C + k] = beta * beta;
+}
+
+int gm_scratch_doubles() { return kGmBlocks * kGmMaxC * 4; }
+
+// gm (device, 5 * C doubles) in/out; scratch: gm_scratch_doubles() doubles
+int est_gaussian_mixture(papof_handle* h, const double* im1, const double* im2, int H, int W, int C, double* gm,
+                         double* scratch) {
+    if (C > kGmMaxC) return PAPOF_EINVAL;
+    for (int it = 0; it < 3; it++) {
+        hipLaunchKernelGGL(k_gm_partial, dim3(kGmBlocks), dim3(kGmThreads), 0, h->stream, im1, im2, (size_t)H * W, C, gm,
+                           scratch);
+        hipLaunchKernelGGL(k_gm_mstep, dim3(1), dim3(64), 0, h->stream, scratch, C, 0.9, gm);
+    }
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+// closes the last phase of a call: a one-thread kernel that only writes the pending stamp (if any)
+int stamp_only(papof_handle* h) {
+    unsigned long long* s = take_stamp(h);
+    if (!s) return PAPOF_OK;
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, h->stream, s);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }

@@ -99,7 +99,12 @@ struct ExactArgs {
              // keeps resident is issued as consecutive launches over ranges of sweeps (sor_solve)
     double nalpha, om1;
     unsigned long long* dbg;  // diagnostics (PAPOF_SOR_DBG): per task 8 time stamps (s_memrealtime, 100 MHz), else null
+    unsigned long long* stamp;  // phase stamp (flow_internal.h: PhaseClock): block 0 writes the 100 MHz clock on entry
 };
+
+__device__ __forceinline__ void stamp_now(unsigned long long* s) {
+    if (s && (blockIdx.x | threadIdx.x) == 0u) *s = __builtin_amdgcn_s_memrealtime();
+}
 
 __device__ __forceinline__ double ld_agent(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -412,6 +417,7 @@ __device__ __forceinline__ bool wait_covered(const ExactArgs& A, const Polls& pl
 template <int R, bool DPP>
 __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     static_assert(R >= 4 && R % 2 == 0, "two markers per iteration");
+    stamp_now(A.stamp);
     const unsigned lane = threadIdx.x;
     // Workgroups are dealt round-robin over the 8 XCDs (blocks x and x + 8 share one; observed, speed only), so with
     // xcd_affine the sweeps of one band all run on one XCD: sweep k+1 re-reads the coefficient cells sweep k read a
@@ -746,6 +752,7 @@ __device__ __forceinline__ void f_run(const ExactArgs& A, const Task& T, const L
 template <int R, bool DPP>
 __global__ __launch_bounds__(64) void k_sor_fused(ExactArgs A) {
     static_assert(R >= 6 && R % 2 == 0, "two markers per iteration; coefficient slots live two extra steps");
+    stamp_now(A.stamp);
     const unsigned lane = threadIdx.x;
     const int pairs = (A.n_sor + 1) >> 1;
     int q, b;
@@ -845,6 +852,7 @@ struct GroupArgs {
     unsigned long long* dbg;  // diagnostics (PAPOF_SOR_DBG): per task {total, wait_covered, lds in, lds out} shader clocks
     unsigned halo_off;  // byte offset of the halo rows from du
     double nalpha, om1;
+    unsigned long long* stamp;  // as ExactArgs::stamp
 };
 
 constexpr int kRing = 16;  // LDS ring slots of (du, dv) per producing wave (>= 2 half-iterations)
@@ -1109,6 +1117,7 @@ __global__ __launch_bounds__(64 * M) void k_sor_group(GroupArgs A) {
     __shared__ unsigned lds_done[M];   // [m]: steps of wave m whose cells are in its ring
     __shared__ unsigned lds_taken[M];  // [m]: steps of ring m the wave after has read
     __shared__ unsigned lds_abort;
+    stamp_now(A.stamp);
     const unsigned lane = threadIdx.x & 63u;
     const int m = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform by construction
     lds_store_lane0((lds_word*)&lds_done[m], 0u);
@@ -1298,6 +1307,7 @@ struct BlockedArgs {
     int hs0;                // index of the first half-sweep of this launch within the solve (its parity = its colour)
     int cw, ch, ntx, nblk;  // core tile size, tiles per row, tiles
     int shift;              // 1: regions start one column further left, so that every region starts on an even column
+    unsigned long long* stamp;  // as ExactArgs::stamp
     double nalpha, om1;
 };
 
@@ -1325,6 +1335,7 @@ template <int MODE, int NW, int RPT, bool VEC>
 __global__ __launch_bounds__(NW * 64) void k_sor_blocked(BlockedArgs A) {
     constexpr int RH = NW * RPT, S = kLanes + 1, CELLS = (RH + 2) * S + 2;
     __shared__ f64x2 lds[2][CELLS];
+    stamp_now(A.stamp);
     const int t = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // Workgroups are dealt round-robin over the 8 XCDs (observed; speed only): give each XCD a contiguous run of tiles so
@@ -1615,6 +1626,7 @@ int sor_blocked_launch(papof_handle* h, const SorPlanes& sp, int H, int W, doubl
     A.hs0 = hs0;
     A.nalpha = -alpha;
     A.om1 = 1 - omega;
+    A.stamp = take_stamp(h);
     // Core tile: the region minus the ghost ring; where `out` reaches an image border no ring is needed on that side, so a
     // plane that fits one region is ONE workgroup with no ghost cells at all, whatever g.
     const bool span_x = out.x0 == 0 && out.x1 == W && W <= RW, span_y = out.y0 == 0 && out.y1 == H && H <= RH;
@@ -1832,6 +1844,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             const int chunk = std::max(1, resident_tasks(h) / (per_g * sd.group));
             for (int g0 = 0; g0 < groups; g0 += chunk) {
                 Ga.g0 = g0;
+                Ga.stamp = take_stamp(h);  // the first launch marks the start of the solve
                 const dim3 ggrid(per_g * std::min(chunk, groups - g0));
                 if (sd.group == 4 && Rg >= 12)
                     hipLaunchKernelGGL((k_sor_group<12, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
@@ -1858,6 +1871,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             const int chunk = std::max(1, resident_tasks(h) / per_q);
             for (int q0 = 0; q0 < pairs; q0 += chunk) {
                 A.k0 = q0;
+                A.stamp = take_stamp(h);
                 const dim3 fgrid(per_q * std::min(chunk, pairs - q0));
                 if (Rf <= 6)
                     hipLaunchKernelGGL((k_sor_fused<6, true>), fgrid, dim3(kLanes), 0, h->stream, A);
@@ -1885,6 +1899,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         const int chunk = std::max(1, resident_tasks(h) / per_k);
         for (int k0 = 0; k0 < n_sor; k0 += chunk) {
             A.k0 = k0;
+            A.stamp = take_stamp(h);
             const dim3 grid(per_k * std::min(chunk, n_sor - k0));
             if (!h->use_dpp)
                 hipLaunchKernelGGL((k_sor_exact<8, false>), grid, block, 0, h->stream, A);

@@ -31,6 +31,8 @@ cdef extern from "papof.h":
         double omega
         int sor_mode
         int phase_timing
+        int interpolation
+        int noise_model
     void papof_default_params(papof_params* p)
     const char* papof_strerror(int code)
     const char* papof_last_error()
@@ -72,6 +74,8 @@ def coarse2fine_flow(np.ndarray[double, ndim=3, mode="c"] Im1 not None,
         elif key == "omega": P.omega = value
         elif key == "sor_mode": P.sor_mode = value
         elif key == "phase_timing": P.phase_timing = value
+        elif key == "interpolation": P.interpolation = value
+        elif key == "noise_model": P.noise_model = value
         else:
             raise TypeError("coarse2fine_flow() got an unexpected keyword argument %r" % key)
     cdef int rc

@@ -33,7 +33,7 @@ def _c(a):
 class OrcParams(ctypes.Structure):
     _fields_ = [("alpha", c_double), ("ratio", c_double), ("n_outer", c_int), ("n_outer_per_level", c_int),
                 ("n_inner", c_int), ("n_sor", c_int), ("n_sor_per_level", c_int), ("omega", c_double),
-                ("sor_mode", c_int)]
+                ("sor_mode", c_int), ("interpolation", c_int), ("noise_model", c_int)]
 
 
 def build_oracle():
@@ -42,7 +42,66 @@ def build_oracle():
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "oracle"])
 
 
-class OracleLib:
+def _split_levels(data, dims, n, c):
+    out, off = [], 0
+    for i in range(n):
+        lw, lh = int(dims[2 * i]), int(dims[2 * i + 1])
+        out.append(data[off:off + lw * lh * c].reshape(lh, lw, c).copy())
+        off += lw * lh * c
+    return out
+
+
+def gm_default(c):
+    """GaussianMixture::reset (src/NoiseModel.h:97-107): alpha .95, sigma .05, beta .5 and their squares, per channel"""
+    return np.concatenate([np.full(c, 0.95), np.full(c, 0.05), np.full(c, 0.5), np.full(c, 0.05) ** 2,
+                           np.full(c, 0.5) ** 2])
+
+
+class _OracleBranches:
+    """The reference's non-default branches on the oracle; mixed into OracleLib."""
+
+    def pyramid_minwidth(self, im, ratio, min_width):
+        im = _c(im)
+        h, w, c = im.shape
+        self.L.orc_pyramid_levels_for_min_width.argtypes = [c_int, c_double, c_int]
+        n = self.L.orc_pyramid_levels_for_min_width(w, ratio, min_width)
+        return self.pyramid(im, ratio, n)
+
+    def coarse2fine_flow_opts(self, im1, im2, levels, interpolation, noise_model):
+        p = self.default_params()
+        p.interpolation, p.noise_model = interpolation, noise_model
+        return self.coarse2fine_flow(im1, im2, levels, p)[:3]
+
+    def smoothflow_sor_opts(self, im1, im2, warp, u, v, alpha, n_outer, n_inner, n_sor, interpolation, noise_model):
+        im1, im2 = _c(im1), _c(im2)
+        warp, u, v = _c(warp).copy(), _c(u).copy(), _c(v).copy()
+        h, w, c = im1.shape
+        lp = np.full(max(c, 8), 0.02)
+        gm = gm_default(c)
+        self.L.orc_smoothflow_sor_ex.argtypes = [_D, _D, _D, _D, _D, c_int, c_int, c_int, c_double, c_int, c_int, c_int,
+                                                 c_double, c_int, _D, _D, c_int, _D]
+        self.L.orc_smoothflow_sor_ex(_p(im1), _p(im2), _p(warp), _p(u), _p(v), h, w, c, alpha, n_outer, n_inner, n_sor,
+                                     1.8, 0, _p(lp), None, interpolation, _p(gm) if noise_model else None)
+        return warp, u, v, gm
+
+    def est_gaussian_mixture(self, im1, im2, gm=None):
+        im1, im2 = _c(im1), _c(im2)
+        h, w, c = im1.shape
+        gm = gm_default(c) if gm is None else _c(gm).copy()
+        self.L.orc_est_gaussian_mixture.argtypes = [_D, _D, ctypes.c_long, c_int, _D, c_double]
+        self.L.orc_est_gaussian_mixture(_p(im1), _p(im2), h * w, c, _p(gm), 0.9)
+        return gm
+
+    def bicubic_warp_noclamp(self, im1, im2, vx, vy):
+        im1, im2, vx, vy = _c(im1), _c(im2), _c(vx), _c(vy)
+        h, w, c = im1.shape
+        out = np.zeros_like(im1)
+        self.L.orc_bicubic_warp_noclamp.argtypes = [_D, _D, _D, _D, c_int, c_int, c_int, _D]
+        self.L.orc_bicubic_warp_noclamp(_p(im1), _p(im2), _p(vx), _p(vy), h, w, c, _p(out))
+        return out
+
+
+class OracleLib(_OracleBranches):
     name = "oracle"
 
     def __init__(self):
@@ -349,6 +408,54 @@ class RefLib:
         vx, vy, wi, t = np.zeros((h, w)), np.zeros((h, w)), np.zeros((h, w, c)), np.zeros(10)
         self.L.ref_coarse2fine_flow(_p(im1), _p(im2), h, w, c, levels, _p(vx), _p(vy), _p(wi), _p(t))
         return vx, vy, wi, t
+
+    # ---- the non-default branches, selected through the reference's public statics (oracle/ref_driver.cpp) ----
+    def pyramid_minwidth(self, im, ratio, min_width):
+        im = _c(im)
+        h, w, c = im.shape
+        dims = np.zeros(128, dtype=np.int32)
+        self.L.ref_pyramid_minwidth.argtypes = [_D, c_int, c_int, c_int, c_double, c_int, _I, _D]
+        n = self.L.ref_pyramid_minwidth(_p(im), h, w, c, ratio, min_width, dims.ctypes.data_as(_I), None)
+        total = sum(int(dims[2 * i]) * int(dims[2 * i + 1]) * c for i in range(n))
+        data = np.zeros(total)
+        self.L.ref_pyramid_minwidth(_p(im), h, w, c, ratio, min_width, dims.ctypes.data_as(_I), _p(data))
+        return _split_levels(data, dims, n, c)
+
+    def coarse2fine_flow_opts(self, im1, im2, levels, interpolation, noise_model):
+        im1, im2 = _c(im1), _c(im2)
+        h, w, c = im1.shape
+        vx, vy, wi = np.zeros((h, w)), np.zeros((h, w)), np.zeros((h, w, c))
+        self.L.ref_coarse2fine_flow_opts.argtypes = [_D, _D, c_int, c_int, c_int, c_int, c_int, c_int, _D, _D, _D]
+        self.L.ref_coarse2fine_flow_opts(_p(im1), _p(im2), h, w, c, levels, interpolation, noise_model, _p(vx), _p(vy),
+                                         _p(wi))
+        return vx, vy, wi
+
+    def smoothflow_sor_opts(self, im1, im2, warp, u, v, alpha, n_outer, n_inner, n_sor, interpolation, noise_model):
+        im1, im2 = _c(im1), _c(im2)
+        warp, u, v = _c(warp).copy(), _c(u).copy(), _c(v).copy()
+        h, w, c = im1.shape
+        gm = gm_default(c)
+        self.L.ref_smoothflow_sor_opts.argtypes = [_D, _D, _D, _D, _D, c_int, c_int, c_int, c_double, c_int, c_int, c_int,
+                                                   c_int, c_int, _D]
+        self.L.ref_smoothflow_sor_opts(_p(im1), _p(im2), _p(warp), _p(u), _p(v), h, w, c, alpha, n_outer, n_inner, n_sor,
+                                       interpolation, noise_model, _p(gm))
+        return warp, u, v, gm
+
+    def est_gaussian_mixture(self, im1, im2, gm=None):
+        im1, im2 = _c(im1), _c(im2)
+        h, w, c = im1.shape
+        gm = gm_default(c) if gm is None else _c(gm).copy()
+        self.L.ref_est_gaussian_mixture.argtypes = [_D, _D, c_int, c_int, c_int, _D]
+        self.L.ref_est_gaussian_mixture(_p(im1), _p(im2), h, w, c, _p(gm))
+        return gm
+
+    def bicubic_warp_noclamp(self, im1, im2, vx, vy):
+        im1, im2, vx, vy = _c(im1), _c(im2), _c(vx), _c(vy)
+        h, w, c = im1.shape
+        out = np.zeros_like(im1)
+        self.L.ref_bicubic_warp_noclamp.argtypes = [_D, _D, _D, _D, c_int, c_int, c_int, _D]
+        self.L.ref_bicubic_warp_noclamp(_p(im1), _p(im2), _p(vx), _p(vy), h, w, c, _p(out))
+        return out
 
     def coarse2fine_flow_sched(self, im1, im2, levels, alpha, ratio, n_outer, outer_step, n_inner, n_sor, sor_step,
                                mode=0, omega=1.8):

@@ -189,6 +189,51 @@ def stage_flow16(lib):
     return {"q": q.astype(np.float64), "vx": dx, "vy": dy}
 
 
+# ----------------------------------------------------------------------------------------------
+# the reference's non-default branches (unreachable from its Python entry point, selected in
+# the untouched reference through its public statics by oracle/ref_driver.cpp)
+# ----------------------------------------------------------------------------------------------
+def _opts(res, levels, interpolation, noise_model):
+    def run(lib):
+        a, b = load_pair(res)
+        vx, vy, wi = lib.coarse2fine_flow_opts(a, b, levels, interpolation, noise_model)
+        return {"vx": vx, "vy": vy, "warpI2": wi}
+    return run
+
+
+def stage_pyramid_minwidth(lib):
+    """GaussianPyramid::ConstructPyramid(image, ratio, minWidth) (src/GaussianPyramid.cpp:47-77)"""
+    a, _ = load_pair("240")
+    out = {}
+    lv = lib.pyramid_minwidth(a, 0.75, 30)  # log(30/240)/log(.75) = 7.2 -> 7 levels
+    out["n"] = np.array([float(len(lv))])
+    for i, x in enumerate(lv):
+        out["L%d" % i] = x
+    lv = lib.pyramid_minwidth(a[:40, :50], 0.5, 12)  # 2.06 -> 2 levels
+    out["r05_n"] = np.array([float(len(lv))])
+    for i, x in enumerate(lv):
+        out["r05_L%d" % i] = x
+    return out
+
+
+def stage_branches(lib):
+    """In-loop bicubic warping (src/OpticalFlow.cpp:517-521, :816) and the Gaussian-mixture noise model (:359-367,
+    :539-591) at the level of one SmoothFlowSOR call."""
+    a, b = load_pair("240")
+    f1 = np.ascontiguousarray(features5(a)[::2, ::2])
+    f2 = np.ascontiguousarray(features5(b)[::2, ::2])
+    h, w, _ = f1.shape
+    z = np.zeros((h, w))
+    vx, vy = _flow(13, h, w, 1.5)
+    out = {"bicubic_noclamp": lib.bicubic_warp_noclamp(f1, f2, vx, vy)}
+    w1, u1, v1, _ = lib.smoothflow_sor_opts(f1, f2, f2, z, z, 0.012, 3, 1, 10, 1, 0)
+    out.update({"bc_warp": w1, "bc_u": u1, "bc_v": v1})
+    out["gm_est"] = lib.est_gaussian_mixture(f1, f2)
+    w2, u2, v2, g2 = lib.smoothflow_sor_opts(f1, f2, f2, z, z, 0.012, 3, 1, 10, 0, 1)
+    out.update({"gm_warp": w2, "gm_u": u2, "gm_v": v2, "gm_para": g2})
+    return out
+
+
 CASES = {
     "e2e_240_L1": _e2e("240", 1),
     "e2e_240_L2": _e2e("240", 2),
@@ -215,6 +260,11 @@ CASES = {
     "stage_laplacian": stage_laplacian,
     "stage_smoothflow": stage_smoothflow,
     "stage_flow16": stage_flow16,
+    "stage_pyramid_minwidth": stage_pyramid_minwidth,
+    "stage_branches": stage_branches,
+    "bicubic_240_L3": _opts("240", 3, 1, 0),
+    "gmixture_240_L3": _opts("240", 3, 0, 1),
+    "bicubic_gmixture_480_L4": _opts("480", 4, 1, 1),
 }
 
 # cases whose oracle run takes > ~15 s on one core; exercised by the CPU suite only when PAPOF_SLOW=1

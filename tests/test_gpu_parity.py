@@ -51,6 +51,61 @@ def test_stage_matches_oracle(gpu, oracle, case):
         _cmp(case + "/" + k, got[k], want[k], TOL_STAGE)
 
 
+# The Gaussian-mixture noise model (src/OpticalFlow.cpp:359-367, :539-591) is the one branch that cannot be bit-compatible:
+# it evaluates exp() (the device library's, <= 1 ulp, not glibc's bits) and sums over all pixels (the reference adds
+# them sequentially, a GPU reduction adds them as a tree).  Policy: the mixture parameters after an EM
+# estimate agree to 1e-12 relative, the flow of whole solves to 1e-6 absolute -- two orders inside BASELINE's 1e-4 bar;
+# the measured distances are printed.
+TOL_GM_PARA = 1e-12
+TOL_GM_SOLVE = 1e-6
+
+
+def test_min_width_pyramid_matches_oracle(gpu, oracle):
+    """GaussianPyramid::ConstructPyramid(image, ratio, minWidth) (src/GaussianPyramid.cpp:47-77): the level count formula,
+    then the same levels -- bit for bit against the oracle (itself pinned to the reference's golden vectors)."""
+    got = cases.CASES["stage_pyramid_minwidth"](gpu)
+    want = cases.CASES["stage_pyramid_minwidth"](oracle)
+    assert set(got) == set(want) and got["n"][0] == 7 and got["r05_n"][0] == 2
+    for k in want:
+        _cmp("stage_pyramid_minwidth/" + k, got[k], want[k], TOL_STAGE)
+    a, _ = cases.load_pair("240")
+    import ctypes
+    from papteam_opticalflow_amd import capi
+    oracle.L.orc_pyramid_levels_for_min_width.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_int]
+    for width, ratio, mw in ((240, 0.75, 30), (1920, 0.75, 16), (240, 0.5, 16), (240, 0.9, 100), (240, 0.2, 30),
+                             (240, 0.75, 239), (960, 0.98, 20), (50, 0.4, 3)):
+        n = ctypes.c_int(0)
+        assert capi.load().papof_pyramid_levels_for_min_width(width, ratio, mw, ctypes.byref(n)) == 0
+        assert n.value == oracle.L.orc_pyramid_levels_for_min_width(width, ratio, mw), (width, ratio, mw)
+
+
+def test_branch_stages_match_oracle(gpu, oracle):
+    """In-loop bicubic warping (bit-exact) and the Gaussian-mixture model (tolerance, see above) at the level of one
+    SmoothFlowSOR call."""
+    got = cases.CASES["stage_branches"](gpu)
+    want = cases.CASES["stage_branches"](oracle)
+    assert set(got) == set(want)
+    for k in ("bicubic_noclamp", "bc_warp", "bc_u", "bc_v"):
+        _cmp("stage_branches/" + k, got[k], want[k], TOL_STAGE)
+    for k in ("gm_est", "gm_para"):
+        rel = float(np.abs(got[k] / want[k] - 1).max())
+        print("%-28s max relative %.3e" % ("stage_branches/" + k, rel))
+        assert rel <= TOL_GM_PARA, (k, rel)
+    for k in ("gm_warp", "gm_u", "gm_v"):
+        _cmp("stage_branches/" + k, got[k], want[k], TOL_GM_SOLVE)
+
+
+@pytest.mark.parametrize("case,tol", [("bicubic_240_L3", TOL_SOLVE), ("gmixture_240_L3", TOL_GM_SOLVE),
+                                      ("bicubic_gmixture_480_L4", TOL_GM_SOLVE)])
+def test_branches_end_to_end_match_reference_golden(gpu, case, tol):
+    """Whole calls with interpolation = Bicubic and / or noise model = Gaussian mixture against what the untouched
+    reference produced with its statics set that way (oracle/ref_driver.cpp::ref_coarse2fine_flow_opts)."""
+    gold = np.load(os.path.join(GOLD, "golden.npz"))
+    got = cases.CASES[case](gpu)
+    for k, a in got.items():
+        _cmp(case + "/" + k + " vs reference", cases.subsample(a), gold["%s|%s" % (case, k)], tol)
+
+
 def test_laplacian_known_answer_on_gpu(gpu):
     """The reference's testLaplacian(3) matrix reproduced by the HIP kernel."""
     expect = np.array([[2, -1, 0, -1, 0, 0, 0, 0, 0], [-1, 3, -1, 0, -1, 0, 0, 0, 0], [0, 0, 1, 0, 0, -1, 0, 0, 0],
@@ -158,7 +213,7 @@ def test_end_to_end_matches_oracle(gpu, oracle, res, levels):
     _cmp("e2e %s L%d vx" % (res, levels), vx, ox, TOL_SOLVE)
     _cmp("e2e %s L%d vy" % (res, levels), vy, oy, TOL_SOLVE)
     _cmp("e2e %s L%d warpI2" % (res, levels), wi, ow, TOL_SOLVE)
-    assert t[9] > 0
+    assert np.all(np.asarray(t) > 0), t  # all ten reference timers are measured on the default call
 
 
 @pytest.mark.parametrize("case", ["e2e_1920_L5", "cfg4_1920_L5", "e2e_960_L5", "cfg4_480_L5", "gray_240_L3",
@@ -301,8 +356,10 @@ def test_pyflow_dropin_entry_point(oracle):
     assert list(timing) == ["Allocation", "Construction", "Phase1_Generate", "Phase2_Derivatives", "Phase3_PsiData",
                             "Phase4_LinearSystem", "Phase5_SOR", "Phase6_Update", "PostProcessing",
                             "Total C++ Execution"]
-    assert all(isinstance(x, str) and float(x) >= 0 for x in timing.values())
-    assert float(timing["Total C++ Execution"]) > 0
+    # the reference fills all ten (src/OpticalFlow.cpp:850-860) and its caller appends them to UniversalTiming.txt
+    # (OpticalFlowCalculation.py:168-191): every one of them is measured on the DEFAULT call
+    assert all(isinstance(x, str) and float(x) > 0 for x in timing.values()), timing
+    assert float(timing["Total C++ Execution"]) >= max(float(v) for k, v in timing.items() if k != "Total C++ Execution")
     assert u.shape == (135, 240) and v.shape == (135, 240) and im2w.shape == (135, 240, 3)
     assert u.dtype == np.float64 and im2w.dtype == np.float64
     flow = np.concatenate((u[..., None], v[..., None]), axis=2)  # what the caller does next (:75)
