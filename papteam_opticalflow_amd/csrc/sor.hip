@@ -1626,7 +1626,7 @@ int sor_blocked_launch(papof_handle* h, const SorPlanes& sp, int H, int W, doubl
     A.hs0 = hs0;
     A.nalpha = -alpha;
     A.om1 = 1 - omega;
-    A.stamp = take_stamp(h);
+    A.stamp = nullptr;
     // Core tile: the region minus the ghost ring; where `out` reaches an image border no ring is needed on that side, so a
     // plane that fits one region is ONE workgroup with no ghost cells at all, whatever g.
     const bool span_x = out.x0 == 0 && out.x1 == W && W <= RW, span_y = out.y0 == 0 && out.y1 == H && H <= RH;
@@ -1844,7 +1844,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             const int chunk = std::max(1, resident_tasks(h) / (per_g * sd.group));
             for (int g0 = 0; g0 < groups; g0 += chunk) {
                 Ga.g0 = g0;
-                Ga.stamp = take_stamp(h);  // the first launch marks the start of the solve
+                Ga.stamp = nullptr;  // no stamp at the head of the critical task (flow_internal.h: PhaseClock)
                 const dim3 ggrid(per_g * std::min(chunk, groups - g0));
                 if (sd.group == 4 && Rg >= 12)
                     hipLaunchKernelGGL((k_sor_group<12, 4, true>), ggrid, dim3(kLanes * 4), 0, h->stream, Ga);
@@ -1871,7 +1871,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             const int chunk = std::max(1, resident_tasks(h) / per_q);
             for (int q0 = 0; q0 < pairs; q0 += chunk) {
                 A.k0 = q0;
-                A.stamp = take_stamp(h);
+                A.stamp = nullptr;
                 const dim3 fgrid(per_q * std::min(chunk, pairs - q0));
                 if (Rf <= 6)
                     hipLaunchKernelGGL((k_sor_fused<6, true>), fgrid, dim3(kLanes), 0, h->stream, A);
@@ -1899,7 +1899,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         const int chunk = std::max(1, resident_tasks(h) / per_k);
         for (int k0 = 0; k0 < n_sor; k0 += chunk) {
             A.k0 = k0;
-            A.stamp = take_stamp(h);
+            A.stamp = nullptr;
             const dim3 grid(per_k * std::min(chunk, n_sor - k0));
             if (!h->use_dpp)
                 hipLaunchKernelGGL((k_sor_exact<8, false>), grid, block, 0, h->stream, A);
