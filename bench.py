@@ -148,7 +148,17 @@ def measure_tiles(args, gpu, dist, rank, world, d1, d2, h, w, c, sched):
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
             sec = float(dt.item()) / args.steps
             n_ex, n_bytes = tr.stats()
+            info = tr.comm_info()  # what RCCL itself says: ncclCommCount / ncclCommUserRank of this rank's communicator
+            per_rank = torch.zeros(world, 3, dtype=torch.float64, device="cuda")
+            per_rank[rank, 0] = sor / args.steps * 1e3
+            per_rank[rank, 1] = info["nranks_seen"]
+            per_rank[rank, 2] = info["rank_seen"]
+            dist.all_reduce(per_rank)
+            pr = per_rank.cpu().numpy()
             result.update({"ms_per_pair": round(sec * 1e3, 4), "value": round(h * w / 1e6 / sec, 4), "unit": "Mpix/s",
+                           "n_ranks_seen": int(pr[:, 1].min()), "ranks_seen": [int(x) for x in pr[:, 2]],
+                           "tile_grid_in_use": "%dx%d" % (info["rows"], info["cols"]),
+                           "sor_ms_per_pair_by_rank": [round(float(x), 4) for x in pr[:, 0]],
                            "sor_ms_per_pair_rank0": round(sor / args.steps * 1e3, 4),
                            "exchanges_per_pair": n_ex, "exchanged_mb_per_pair_rank0": round(n_bytes / 1e6, 3)})
             if rank == 0:  # the same solve on one GPU: time, and the tiled result must be bit-identical to it

@@ -192,6 +192,9 @@ int papof_tiles_flow_device(papof_tiles* t, const double* d_im1, const double* d
                             double* d_vx, double* d_vy, double* d_warpI2 /* rank 0 only; may be NULL elsewhere */,
                             double timing_sec[PAPOF_N_TIMERS]);
 int papof_tiles_stats(const papof_tiles* t, long* exchanges, size_t* bytes); /* of the last call, this rank */
+/* what the TRANSPORT reports about the group (RCCL: ncclCommCount / ncclCommUserRank of this member's communicator), and
+ * the tile grid / ghost depth in use: lets a multi-GPU bench line show that RCCL saw N ranks and the rows x cols split */
+int papof_tiles_comm_info(const papof_tiles* t, int* nranks_seen, int* rank_seen, int* rows, int* cols, int* halo);
 void papof_tiles_destroy(papof_tiles* t);
 
 /* hipGraph replay of whole calls (also PAPOF_GRAPH=1 when the handle is created).  A call with given arguments runs

@@ -49,7 +49,7 @@ SYMBOLS = [
     "papof_tiles_flow_device", "papof_tiles_stats", "papof_tiles_destroy", "papof_flow_quantize16",
     "papof_flow_dequantize16", "papof_flow_to_bgr", "papof_set_graph_mode", "papof_sor_plan",
     "papof_pyramid_levels_for_min_width", "papof_stage_smoothflow_ex", "papof_stage_est_gaussian_mixture",
-    "papof_stage_bicubic_warp_ex",
+    "papof_stage_bicubic_warp_ex", "papof_tiles_comm_info",
 ]
 
 
@@ -544,6 +544,12 @@ class TileRank:
         n, b = ctypes.c_long(0), ctypes.c_size_t(0)
         _chk(self.gpu.L.papof_tiles_stats(self.t, ctypes.byref(n), ctypes.byref(b)), "papof_tiles_stats")
         return n.value, b.value
+
+    def comm_info(self):
+        """{nranks_seen, rank_seen, rows, cols, halo}: the first two as the transport reports them (RCCL communicator)"""
+        v = [c_int(0) for _ in range(5)]
+        _chk(self.gpu.L.papof_tiles_comm_info(self.t, *[ctypes.byref(x) for x in v]), "papof_tiles_comm_info")
+        return dict(zip(("nranks_seen", "rank_seen", "rows", "cols", "halo"), (x.value for x in v)))
 
     def close(self):
         if self.t:

@@ -89,6 +89,12 @@ struct Msg {
 struct Transport {
     int rank = 0, nranks = 1;
     virtual ~Transport() {}
+    // what the transport itself says about the group (RCCL: ncclCommCount / ncclCommUserRank of the communicator)
+    virtual int seen(int* n, int* r) const {
+        *n = nranks;
+        *r = rank;
+        return PAPOF_OK;
+    }
     // Everything enqueued on h->stream before the call is visible to the sends; everything enqueued after it sees the
     // received data.
     virtual int exchange(papof_handle* h, const std::vector<Msg>& sends, const std::vector<Msg>& recvs) = 0;
@@ -99,6 +105,8 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -122,6 +130,8 @@ const RcclApi* rccl() {
         PAPOF_SYM(GetUniqueId, "ncclGetUniqueId");
         PAPOF_SYM(CommInitRank, "ncclCommInitRank");
         PAPOF_SYM(CommDestroy, "ncclCommDestroy");
+        PAPOF_SYM(CommCount, "ncclCommCount");
+        PAPOF_SYM(CommUserRank, "ncclCommUserRank");
         PAPOF_SYM(GroupStart, "ncclGroupStart");
         PAPOF_SYM(GroupEnd, "ncclGroupEnd");
         PAPOF_SYM(Send, "ncclSend");
@@ -149,6 +159,12 @@ struct RcclTransport : Transport {
     ncclComm_t comm = nullptr;
     ~RcclTransport() override {
         if (comm) api->CommDestroy(comm);
+    }
+    int seen(int* n, int* r) const override {
+        if (!api->CommCount || !api->CommUserRank) return PAPOF_EDEVICE;
+        PAPOF_NCCL(api, api->CommCount(comm, n));
+        PAPOF_NCCL(api, api->CommUserRank(comm, r));
+        return PAPOF_OK;
     }
     int exchange(papof_handle* h, const std::vector<Msg>& sends, const std::vector<Msg>& recvs) override {
         if (sends.empty() && recvs.empty()) return PAPOF_OK;
@@ -392,13 +408,46 @@ int tiles_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     double* tmp_a = A.f64(np0 * C);
     double* tmp_b = A.f64(np0 * C);
     if (A.overflow) return PAPOF_ENOMEM;
-    PAPOF_TRY(hwc_to_planar(h, d_im1, L[0].p1, H, W, C));
-    PAPOF_TRY(hwc_to_planar(h, d_im2, L[0].p2, H, W, C));
-    PAPOF_TRY(build_pyramid(h, L, plan, C, false, tmp_a, tmp_b));
-    PAPOF_TRY(build_pyramid(h, L, plan, C, true, tmp_a, tmp_b));
+    // Replicated, flow-independent work -- both pyramids and the features of every level (src/OpticalFlow.cpp:757-758,
+    // :797-798) -- goes to the handle's PREPARATION stream, coarsest level first, beside the coarse levels' solves on the
+    // main stream (as flow_device does): on N GPUs the per-rank solver work shrinks with N, this part does not (rocprof,
+    // one rank: 1.1 of 6.3 ms), so it must not sit on the critical path.  One event per level orders the two streams.
+    std::vector<double*> F1(levels), F2(levels);
+    for (int k = 0; k < levels; k++) {
+        const size_t n = (size_t)L[k].w * L[k].h * fc;
+        F1[k] = A.f64(n);
+        F2[k] = A.f64(n);
+    }
+    if (A.overflow) return PAPOF_ENOMEM;
+    const bool overlap = h->overlap_prep && h->prep_stream != nullptr;
+    while (h->sync_events.size() < (size_t)levels + 2) {
+        hipEvent_t e;
+        PAPOF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->sync_events.push_back(e);
+    }
+    {
+        hipStream_t const main_stream = h->stream;
+        if (overlap) {  // after whatever the caller queued on the main stream (the frame uploads)
+            PAPOF_HIP(hipEventRecord(h->sync_events[levels + 1], main_stream));
+            PAPOF_HIP(hipStreamWaitEvent(h->prep_stream, h->sync_events[levels + 1], 0));
+            h->stream = h->prep_stream;  // the launch wrappers enqueue on h->stream
+        }
+        int rc = hwc_to_planar(h, d_im1, L[0].p1, H, W, C);
+        if (rc == PAPOF_OK) rc = hwc_to_planar(h, d_im2, L[0].p2, H, W, C);
+        if (rc == PAPOF_OK) rc = build_pyramid(h, L, plan, C, false, tmp_a, tmp_b);
+        if (rc == PAPOF_OK) rc = build_pyramid(h, L, plan, C, true, tmp_a, tmp_b);
+        for (int k = levels - 1; k >= 0 && rc == PAPOF_OK; k--) {
+            rc = im2feature(h, L[k].p1, F1[k], L[k].h, L[k].w, C);
+            if (rc == PAPOF_OK) rc = im2feature(h, L[k].p2, F2[k], L[k].h, L[k].w, C);
+            if (rc == PAPOF_OK && overlap && hipEventRecord(h->sync_events[k], h->stream) != hipSuccess) rc = PAPOF_EDEVICE;
+        }
+        h->stream = main_stream;
+        if (rc != PAPOF_OK) {
+            if (overlap) hipStreamSynchronize(h->prep_stream);
+            return rc;
+        }
+    }
 
-    double* f1 = A.f64(np0 * fc);
-    double* f2 = A.f64(np0 * fc);
     double* warp = A.f64(np0 * fc);
     double* u = A.f64(np0);
     double* v = A.f64(np0);
@@ -426,8 +475,8 @@ int tiles_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
         const RectOf own = [&](int r) { return tile_rect(t.grid, r, lw, lh); };
         const Rect T = own(me);
         const Rect Tu = grow(T, HU, lw, lh);  // where this rank keeps (u, v) and the warped features valid
-        PAPOF_TRY(im2feature(h, L[k].p1, f1, lh, lw, C));  // replicated (src/OpticalFlow.cpp:797-798)
-        PAPOF_TRY(im2feature(h, L[k].p2, f2, lh, lw, C));
+        const double *f1 = F1[k], *f2 = F2[k];  // replicated, prepared on the other stream
+        if (overlap) PAPOF_HIP(hipStreamWaitEvent(h->stream, h->sync_events[k], 0));
         if (k == levels - 1) {  // :801-806
             PAPOF_HIP(hipMemsetAsync(u, 0, np * sizeof(double), h->stream));
             PAPOF_HIP(hipMemsetAsync(v, 0, np * sizeof(double), h->stream));
@@ -682,6 +731,18 @@ int papof_tiles_stats(const papof_tiles* t, long* exchanges, size_t* bytes) {
     if (!t) return PAPOF_EINVAL;
     if (exchanges) *exchanges = t->exchanges;
     if (bytes) *bytes = t->exchanged_bytes;
+    return PAPOF_OK;
+}
+
+int papof_tiles_comm_info(const papof_tiles* t, int* nranks_seen, int* rank_seen, int* rows, int* cols, int* halo) {
+    if (!t || !t->tp) return PAPOF_EINVAL;
+    int n = 0, r = 0;
+    PAPOF_TRY(t->tp->seen(&n, &r));
+    if (nranks_seen) *nranks_seen = n;
+    if (rank_seen) *rank_seen = r;
+    if (rows) *rows = t->grid.rows;
+    if (cols) *cols = t->grid.cols;
+    if (halo) *halo = t->halo;
     return PAPOF_OK;
 }
 

@@ -148,4 +148,6 @@ def test_bench_tiles_reporting_path_single_rank():
     t = r["tiles"]
     assert "error" not in t, t
     assert t["grid"] == "1x1" and t["bit_identical_to_one_gpu_redblack"] is True and t["value"] > 0
+    assert t["n_ranks_seen"] == 1 and t["ranks_seen"] == [0] and t["tile_grid_in_use"] == "1x1"
+    assert len(t["sor_ms_per_pair_by_rank"]) == 1 and t["sor_ms_per_pair_by_rank"][0] > 0
     assert r["scaling"] == "weak" and t["scaling"] == "strong" and r["value"] > 0
