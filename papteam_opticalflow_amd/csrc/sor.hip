@@ -1469,16 +1469,46 @@ __global__ __launch_bounds__(NW * 64) void k_sor_blocked(BlockedArgs A) {
         const auto half = [&](auto PARC, int m, int c) __attribute__((always_inline)) {
             constexpr int PAR = decltype(PARC)::value;
             const int fx0 = ox0 * (m + 1), fx1 = rw - ox1 * (m + 1), fy0 = oy0 * (m + 1), fy1 = rh - oy1 * (m + 1);
-            static_for<RPT>([&](auto RR) __attribute__((always_inline)) {
-                constexpr int rr = decltype(RR)::value;
-                constexpr int p = (PAR + rr) & 1;
-                const int r = r0 + rr;
-                if (r >= fy0 && r < fy1) {  // wave-uniform
-                    const f64x2 nw = cell(RR, std::integral_constant<int, p>{}, c);
-                    const int lc = 2 * t + p;
-                    if (lc >= fx0 && lc < fx1) lds[c][idx0 + rr * S] = nw;
-                }
-            });
+            if (r0 + RPT <= fy0 || r0 >= fy1) {  // wave-uniform: none of this wave's rows is inside the frame any more
+                __syncthreads();
+                return;
+            }
+            if constexpr (NW < 16) {
+                // IL rows are computed in ONE basic block (the frame test only predicates the stores): the cell updates are
+                // independent 14-deep fp64 chains, and interleaved they fill the issue slots a single chain leaves empty
+                // -- a per-row branch kept them apart (SQ counters: 31 % of a wave's cycles were issue stalls).  Measured:
+                // -10 % per solve for the 8-wave shapes (256-register budget: all rows at once); 12 waves (168 registers)
+                // interleave two rows at a time.
+                constexpr int IL = NW == 12 ? 2 : RPT;
+                static_assert(RPT % IL == 0, "row groups");
+                static_for<RPT / IL>([&](auto GG) __attribute__((always_inline)) {
+                    constexpr int g0 = decltype(GG)::value * IL;
+                    f64x2 nw[IL];
+                    static_for<IL>([&](auto QQ) __attribute__((always_inline)) {
+                        constexpr int rr = g0 + decltype(QQ)::value;
+                        nw[decltype(QQ)::value] = cell(std::integral_constant<int, rr>{}, std::integral_constant<int, (PAR + rr) & 1>{}, c);
+                    });
+                    static_for<IL>([&](auto QQ) __attribute__((always_inline)) {
+                        constexpr int rr = g0 + decltype(QQ)::value;
+                        constexpr int p = (PAR + rr) & 1;
+                        const int r = r0 + rr, lc = 2 * t + p;
+                        if (r >= fy0 && r < fy1 && lc >= fx0 && lc < fx1) lds[c][idx0 + rr * S] = nw[decltype(QQ)::value];
+                    });
+                });
+            } else {
+                // 16 waves have 128 registers each, 82 of them coefficients: interleaving three rows spills (measured
+                // +40 %); one row at a time, and four waves per SIMD fill each other's stalls instead
+                static_for<RPT>([&](auto RR) __attribute__((always_inline)) {
+                    constexpr int rr = decltype(RR)::value;
+                    constexpr int p = (PAR + rr) & 1;
+                    const int r = r0 + rr;
+                    if (r >= fy0 && r < fy1) {  // wave-uniform
+                        const f64x2 nw = cell(RR, std::integral_constant<int, p>{}, c);
+                        const int lc = 2 * t + p;
+                        if (lc >= fx0 && lc < fx1) lds[c][idx0 + rr * S] = nw;
+                    }
+                });
+            }
             __syncthreads();
         };
         for (int m = 0; m < A.g; m++) {
@@ -1576,18 +1606,19 @@ static BlockedShape blocked_shape_any(const papof_handle* h, int H, int W) {
     if (h->rb_shape == 2) return {8, 4};
     if (h->rb_shape == 3) return {4, 6};
     if (h->rb_shape == 4) return {16, 3};
-    // measured (tools/rb_sweep.py, profiles/r02_rb_shape_depth_sweep.txt): 16 waves x 3 rows beats 8 x 6 on every plane
-    // (four waves per SIMD hide the LDS latency of a half-sweep), the smaller 8 x 4 region wins below ~300 k cells (more
-    // workgroups for the same plane)
+    if (h->rb_shape == 5) return {12, 4};
+    // measured (tools/rb_sweep.py, profiles/r02_rb_shape_depth_sweep*.txt): 12 waves x 4 rows (two rows interleaved per
+    // wave, three waves per SIMD) and 16 x 3 beat 8 x 6 on every plane, the smaller 8 x 4 region wins below ~300 k cells
+    // (more workgroups for the same plane)
     if (W <= 128 && H <= 24) return {4, 6};
     if (W <= 128 && H <= 32) return {8, 4};
-    if ((size_t)H * W >= (size_t)300 * 1000) return {16, 3};
+    if ((size_t)H * W >= (size_t)300 * 1000) return {12, 4};
     return {8, 4};
 }
 static BlockedShape blocked_shape(const papof_handle* h, int mode, int H, int W) {
     const BlockedShape bs = blocked_shape_any(h, H, W);
     // Jacobi keeps a sweep's new values of all 2 * RPT cells in registers beside the coefficients: no 8 x 6 variant
-    if (mode == PAPOF_SOR_JACOBI && ((bs.nw == 8 && bs.rpt == 6) || bs.nw == 16)) return {8, 4};
+    if (mode == PAPOF_SOR_JACOBI && ((bs.nw == 8 && bs.rpt == 6) || bs.nw >= 12)) return {8, 4};
     return bs;
 }
 
@@ -1655,6 +1686,8 @@ int sor_blocked_launch(papof_handle* h, const SorPlanes& sp, int H, int W, doubl
             PAPOF_BLOCKED(PAPOF_SOR_REDBLACK, 8, 4);
         else if (bs.nw == 4 && bs.rpt == 6)
             PAPOF_BLOCKED(PAPOF_SOR_REDBLACK, 4, 6);
+        else if (bs.nw == 12 && bs.rpt == 4)
+            PAPOF_BLOCKED(PAPOF_SOR_REDBLACK, 12, 4);
         else
             PAPOF_BLOCKED(PAPOF_SOR_REDBLACK, 16, 3);
     } else {
