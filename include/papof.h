@@ -210,6 +210,14 @@ int papof_dev_free(papof_handle* h, void* p);
 int papof_dev_upload(papof_handle* h, void* dst, const void* src, size_t bytes);
 int papof_dev_download(papof_handle* h, void* dst, const void* src, size_t bytes);
 void* papof_stream(papof_handle* h); /* the hipStream_t every kernel of this handle is launched on */
+/* Page-locked host memory for RESULT arrays (hipHostMalloc).  The reference's pyflow.pyx allocates vx, vy, warpI2 itself
+ * for every call (np.zeros, Code/Serial/pyflow.pyx:44-52): 83 MB of fresh pages per 1080p pair, i.e. ~20 k first-touch
+ * page faults, a staged device-to-host copy, and an munmap when the caller drops them.  A binding that takes its result
+ * arrays from here (and recycles them when they are garbage-collected: papteam_opticalflow_amd/dropin/pyflow.pyx,
+ * capi.py) gets the results by direct DMA into memory that is already resident.  Any host pointer works as an output
+ * of papof_flow / papof_coarse2fine_flow; these are merely the fastest ones. */
+int papof_host_alloc(size_t bytes, void** out);
+int papof_host_free(void* p);
 
 /* ---- stage entry points (host buffers, reference HWC layout): one per reference function on the path,
  * used by the parity tests to check each kernel in isolation against the oracle. ---- */

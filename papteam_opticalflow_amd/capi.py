@@ -49,7 +49,7 @@ SYMBOLS = [
     "papof_tiles_flow_device", "papof_tiles_stats", "papof_tiles_destroy", "papof_flow_quantize16",
     "papof_flow_dequantize16", "papof_flow_to_bgr", "papof_set_graph_mode", "papof_sor_plan",
     "papof_pyramid_levels_for_min_width", "papof_stage_smoothflow_ex", "papof_stage_est_gaussian_mixture",
-    "papof_stage_bicubic_warp_ex", "papof_tiles_comm_info",
+    "papof_stage_bicubic_warp_ex", "papof_tiles_comm_info", "papof_host_alloc", "papof_host_free",
 ]
 
 
@@ -133,9 +133,55 @@ def load():
     L.papof_stage_est_gaussian_mixture.argtypes = [c_void_p, _D, _D, c_int, c_int, c_int, _D]
     L.papof_stage_bicubic_warp_ex.argtypes = [c_void_p, _D, _D, _D, _D, c_int, c_int, c_int, c_int, _D]
     L.papof_pyramid_levels_for_min_width.argtypes = [c_int, c_double, c_int, ctypes.POINTER(c_int)]
+    L.papof_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(c_void_p)]
+    L.papof_host_free.argtypes = [c_void_p]
     L.papof_sor_plan.argtypes = [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     _lib = L
     return L
+
+
+# ---- result arrays in page-locked memory, recycled when the caller drops them (include/papof.h: papof_host_alloc) ----
+_pinned_pool = {}       # nbytes -> [address, ...] ready for reuse
+_pinned_live = [0]      # bytes currently owned by callers
+
+
+class _PinnedBlock(object):
+    """Owns one pinned allocation; returns it to the pool when the numpy array built on it is garbage-collected."""
+    __slots__ = ("addr", "nbytes", "__weakref__")
+
+    def __init__(self, addr, nbytes):
+        self.addr, self.nbytes = addr, nbytes
+
+    def __del__(self):
+        try:
+            _pinned_live[0] -= self.nbytes
+            lst = _pinned_pool.setdefault(self.nbytes, [])
+            if len(lst) < 6:
+                lst.append(self.addr)
+            else:
+                load().papof_host_free(c_void_p(self.addr))
+        except Exception:  # interpreter shutdown
+            pass
+
+
+def result_array(shape):
+    """float64 array for (vx, vy, warpI2): pinned and recycled (PAPOF_PINNED_OUT=0: plain np.zeros).  Every element is
+    overwritten by the call it is handed to, as the reference overwrites its np.zeros arrays."""
+    nbytes = 8 * int(np.prod(shape))
+    if os.environ.get("PAPOF_PINNED_OUT", "1") == "0" or nbytes < (1 << 20) or _pinned_live[0] + nbytes > (1 << 30):
+        return np.zeros(shape)
+    lst = _pinned_pool.get(nbytes)
+    if lst:
+        addr = lst.pop()
+    else:
+        p = c_void_p()
+        if load().papof_host_alloc(ctypes.c_size_t(nbytes), ctypes.byref(p)) != 0 or not p.value:
+            return np.zeros(shape)
+        addr = p.value
+    buf = (ctypes.c_char * nbytes).from_address(addr)
+    buf._papof_block = _PinnedBlock(addr, nbytes)  # the array keeps `buf` alive, `buf` keeps the block alive
+    _pinned_live[0] += nbytes
+    return np.frombuffer(buf, dtype=np.float64).reshape(shape)
 
 
 def default_params(**overrides):
@@ -216,7 +262,7 @@ class Papof:
         if im1.shape != im2.shape:
             raise ValueError("Im1 %r and Im2 %r differ in shape" % (im1.shape, im2.shape))
         h, w, c = im1.shape
-        vx, vy, wi, t = np.zeros((h, w)), np.zeros((h, w)), np.zeros((h, w, c)), np.zeros(N_TIMERS)
+        vx, vy, wi, t = result_array((h, w)), result_array((h, w)), result_array((h, w, c)), np.zeros(N_TIMERS)
         pp = ctypes.byref(params) if params is not None else None
         _chk(self.L.papof_flow(self.h, _p(im1), _p(im2), h, w, c, levels, pp, _p(vx), _p(vy), _p(wi), _p(t)),
              "papof_flow")
@@ -229,7 +275,7 @@ class Papof:
         if im1.shape != im2.shape:
             raise ValueError("Im1 %r and Im2 %r differ in shape" % (im1.shape, im2.shape))
         h, w, c = im1.shape
-        vx, vy, wi, t = np.zeros((h, w)), np.zeros((h, w)), np.zeros((h, w, c)), np.zeros(N_TIMERS)
+        vx, vy, wi, t = result_array((h, w)), result_array((h, w)), result_array((h, w, c)), np.zeros(N_TIMERS)
         pp = ctypes.byref(params) if params is not None else None
         _chk(self.L.papof_flow_u8(self.h, _pb(im1), _pb(im2), h, w, c, levels, pp, _p(vx), _p(vy), _p(wi), _p(t)),
              "papof_flow_u8")

@@ -232,6 +232,9 @@ struct papof_handle {
     size_t stage_dev_bytes = 0;
     char* pin = nullptr;
     size_t pin_bytes = 0;
+    int host_copy = 1;               // PAPOF_HOST_COPY: 1 = hipMemcpyAsync straight from / to the caller's memory (the runtime's
+                                     // pageable path runs at 55 GB/s here; pinned result arrays are direct DMA), 0 = our pinned
+                                     // bounce pipeline of round 1 (0.4-0.6 ms slower per 1080p call, same-box A/B)
     int host_threads = 6;            // threads used to move pageable user buffers to / from the pinned buffers
     papof::CopyPool* pool = nullptr; // created by the first host-buffer call
     // hipGraph replay of whole calls (PAPOF_GRAPH=1 / papof_set_graph_mode): for small frames a call is hundreds of

@@ -37,9 +37,67 @@ cdef extern from "papof.h":
     const char* papof_strerror(int code)
     const char* papof_last_error()
     const char* papof_timing_key(int index)
+    int papof_host_alloc(size_t nbytes, void** out)
+    int papof_host_free(void* p)
     int papof_coarse2fine_flow(const double* im1, const double* im2, int h, int w, int c, int pyramid_levels,
                                const papof_params* params, double* vx, double* vy, double* warpI2,
                                double* timing_sec) nogil
+
+# ---- result arrays in page-locked memory, recycled when the caller drops them (include/papof.h: papof_host_alloc).
+# The reference allocates vx, vy, warpI2 with np.zeros for every call (Code/Serial/pyflow.pyx:44-52); every element is
+# overwritten by the call, so recycled memory gives the same arrays -- without 83 MB of first-touch page faults, a staged
+# copy and an munmap per 1080p pair.  PAPOF_PINNED_OUT=0 (or more than 1 GiB of such arrays alive) falls back to np.zeros.
+import os as _os
+from cpython.ref cimport Py_INCREF
+from libc.stdint cimport uintptr_t
+
+_pool = {}        # nbytes -> [pointer, ...] ready for reuse
+_live_bytes = 0   # bytes of pinned result arrays currently owned by callers
+_PINNED = _os.environ.get("PAPOF_PINNED_OUT", "1") != "0"
+
+
+cdef class _PinnedBlock:
+    cdef void* ptr
+    cdef size_t nbytes
+
+    def __dealloc__(self):
+        global _live_bytes
+        if self.ptr != NULL:
+            _live_bytes -= self.nbytes
+            lst = _pool.setdefault(self.nbytes, [])
+            if len(lst) < 6:
+                lst.append(<uintptr_t> self.ptr)
+            else:
+                papof_host_free(self.ptr)
+            self.ptr = NULL
+
+
+cdef object _result_array(tuple shape):
+    global _live_bytes
+    cdef size_t nbytes = 8
+    for d in shape:
+        nbytes *= <size_t> d
+    if not _PINNED or nbytes < (1 << 20) or _live_bytes + nbytes > (1 << 30):
+        return np.zeros(shape, dtype=np.float64)
+    cdef void* p = NULL
+    lst = _pool.get(nbytes)
+    if lst:
+        p = <void*> <uintptr_t> lst.pop()
+    elif papof_host_alloc(nbytes, &p) != 0 or p == NULL:
+        return np.zeros(shape, dtype=np.float64)
+    cdef _PinnedBlock blk = _PinnedBlock.__new__(_PinnedBlock)
+    blk.ptr = p
+    blk.nbytes = nbytes
+    _live_bytes += nbytes
+    cdef np.npy_intp dims[3]
+    cdef int nd = len(shape)
+    for i in range(nd):
+        dims[i] = shape[i]
+    arr = np.PyArray_SimpleNewFromData(nd, dims, np.NPY_FLOAT64, p)
+    Py_INCREF(blk)
+    np.PyArray_SetBaseObject(arr, blk)
+    return arr
+
 
 SOR_EXACT = 0
 SOR_REDBLACK = 1
@@ -57,9 +115,9 @@ def coarse2fine_flow(np.ndarray[double, ndim=3, mode="c"] Im1 not None,
                          % (Im2.shape[0], Im2.shape[1], Im2.shape[2], h, w, c))
     if pyramidLevels < 1:
         raise ValueError("pyramidLevels must be >= 1")
-    cdef np.ndarray[double, ndim=2, mode="c"] vx = np.zeros((h, w), dtype=np.float64)
-    cdef np.ndarray[double, ndim=2, mode="c"] vy = np.zeros((h, w), dtype=np.float64)
-    cdef np.ndarray[double, ndim=3, mode="c"] warpI2 = np.zeros((h, w, c), dtype=np.float64)
+    cdef np.ndarray[double, ndim=2, mode="c"] vx = _result_array((h, w))
+    cdef np.ndarray[double, ndim=2, mode="c"] vy = _result_array((h, w))
+    cdef np.ndarray[double, ndim=3, mode="c"] warpI2 = _result_array((h, w, c))
     cdef double timing[10]
     cdef papof_params P
     papof_default_params(&P)

@@ -21,7 +21,13 @@ def timeit(name, fn, n=4):
     for _ in range(n): fn()
     print("%-44s %.2f ms" % (name, (time.perf_counter() - t0) / n * 1e3), flush=True)
 timeit("alloc np.zeros x3 + touch", lambda: [x.fill(0) for x in (np.zeros((h, w)), np.zeros((h, w)), np.zeros((h, w, c)))])
-timeit("f64 in, fresh outputs (wrapper)", lambda: g.coarse2fine_flow(a, b, 5, P))
+timeit("f64 in, wrapper (pinned recycled outputs)", lambda: g.coarse2fine_flow(a, b, 5, P))
+os.environ["PAPOF_PINNED_OUT"] = "0"
+timeit("f64 in, wrapper (fresh np.zeros outputs)", lambda: g.coarse2fine_flow(a, b, 5, P))
+os.environ["PAPOF_PINNED_OUT"] = "1"
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "papteam_opticalflow_amd", "dropin"))
+import pyflow
+timeit("pyflow.coarse2fine_flow (the drop-in)", lambda: pyflow.coarse2fine_flow(a, b, 5, n_outer=3, n_outer_per_level=0, n_sor=30, n_sor_per_level=0))
 timeit("f64 in, reused outputs (C ABI)", lambda: g.L.papof_flow(g.h, p(a), p(b), h, w, c, 5, ctypes.byref(P), p(vx), p(vy), p(wi), p(t)))
 timeit("u8 in, reused outputs (C ABI)", lambda: g.L.papof_flow_u8(g.h, pb(a8), pb(b8), h, w, c, 5, ctypes.byref(P), p(vx), p(vy), p(wi), p(t)))
 d1, d2 = g.dev_alloc(a.nbytes), g.dev_alloc(a.nbytes)
