@@ -2,8 +2,8 @@
 // that replaces OpticalFlow::Coarse2FineFlow (/root/reference/Code/Serial/src/OpticalFlow.cpp:735-903)
 // and Coarse2FineFlowWrapper (src/Coarse2FineFlowWrapper.cpp:14-51).
 //
-// One call = one H2D of the two frames, every pyramid level / outer iteration / sweep on the device
-// (single stream, no host round trip in between), one D2H of vx, vy, warpI2.
+// One call = one H2D of the two frames, every pyramid level / outer iteration / sweep on the device (a main stream and a
+// preparation stream for the flow-independent work, no host round trip in between), one D2H of vx, vy, warpI2.
 #include <algorithm>
 #include <chrono>
 #include <cmath>

@@ -52,8 +52,10 @@
 //       `s_waitcnt vmcnt(0)`; consumers poll relaxed, one iteration ahead.  Counters are zeroed by a memset node
 //       before every launch, every spin is bounded, and a timeout raises an abort word (PAPOF_ETIMEOUT).
 //
-// PAPOF_SOR_REDBLACK / PAPOF_SOR_JACOBI -- one launch per half-sweep / sweep on row-major planes;
-//   throughput and correctness-gate modes whose results differ from the reference's order.
+// PAPOF_SOR_REDBLACK / PAPOF_SOR_JACOBI -- throughput and correctness-gate modes whose results differ from the
+//   reference's order.  One LDS-tiled, temporally blocked kernel (k_sor_blocked, documented where it is
+//   defined): a workgroup keeps a region of the row-major planes on chip for ~10 half-sweeps per launch.  The first
+//   implementation -- one launch per half-sweep / sweep straight on the planes -- is kept as a cross-check (PAPOF_RB_NAIVE).
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>

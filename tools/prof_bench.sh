@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for one bench.py command line: kernel-trace statistics + two PMC passes (FETCH_SIZE, WRITE_SIZE).
-# usage: tools/prof_rb.sh <tag> <bench args...>      outputs under gpurun_out/<tag>_*
+# usage: tools/prof_bench.sh <tag> <bench args...>      outputs under gpurun_out/<tag>_*
 set -e
 tag=$1; shift
 cd "$(dirname "$0")/.."
