@@ -157,3 +157,49 @@ def test_graph_mode_replays_the_same_bits(gpu, oracle):
         assert all(np.array_equal(x, y) for x, y in zip(got[:3], want01))
     finally:
         g.close()
+
+
+def test_pinned_result_arrays_are_recycled_and_hold_the_same_results(monkeypatch):
+    """The Python bindings take (vx, vy, warpI2) from a pool of page-locked memory (papof_host_alloc) and get the memory
+    back when the caller drops the arrays: same results as with plain np.zeros arrays, ordinary writable numpy arrays,
+    and the second call reuses the first call's memory once it has been dropped."""
+    import gc
+    import sys
+    import os
+    from papteam_opticalflow_amd import Papof, capi
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "papteam_opticalflow_amd", "dropin"))
+    import pyflow
+    rng = np.random.default_rng(5)
+    a = np.ascontiguousarray(rng.uniform(0, 1, (300, 500, 3)))  # 1.2 MB per flow plane: above the pool's 1-MiB floor
+    b = np.ascontiguousarray(np.clip(np.roll(a, (1, 2), (0, 1)) + rng.normal(0, 0.01, a.shape), 0, 1))
+    g = Papof(0)
+    try:
+        monkeypatch.setenv("PAPOF_PINNED_OUT", "0")
+        plain = g.coarse2fine_flow(a, b, 3)[:3]
+        monkeypatch.setenv("PAPOF_PINNED_OUT", "1")
+        vx, vy, wi, _ = g.coarse2fine_flow(a, b, 3)
+        assert all(np.array_equal(x, y) for x, y in zip((vx, vy, wi), plain))
+        assert vx.flags.writeable and vx.dtype == np.float64 and vx.flags.c_contiguous
+        vx += 1.0  # an ordinary array
+        addr = vx.ctypes.data
+        live = capi._pinned_live[0]
+        assert live >= vx.nbytes + vy.nbytes + wi.nbytes
+        view = vx[10:20]  # a view keeps the block alive
+        del vx
+        gc.collect()
+        assert capi._pinned_live[0] == live and view[0, 0] == plain[0][10, 0] + 1.0
+        del view, vy, wi
+        gc.collect()
+        assert capi._pinned_live[0] == live - 300 * 500 * 8 * 5
+        again = g.coarse2fine_flow(a, b, 3)
+        assert addr in (again[0].ctypes.data, again[1].ctypes.data)  # recycled
+        assert np.array_equal(again[0], plain[0])
+        t, u, v, w2 = pyflow.coarse2fine_flow(a, b, 3)  # the Cython drop-in has its own pool of the same kind
+        assert np.array_equal(u, plain[0]) and np.array_equal(w2, plain[2]) and u.flags.writeable
+        del u, v, w2
+        gc.collect()
+        t, u, v, w2 = pyflow.coarse2fine_flow(a, b, 3)
+        assert np.array_equal(v, plain[1])
+    finally:
+        g.close()
