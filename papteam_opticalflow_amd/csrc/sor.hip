@@ -1614,6 +1614,7 @@ static BlockedShape blocked_shape_any(const papof_handle* h, int H, int W) {
     // (more workgroups for the same plane)
     if (W <= 128 && H <= 24) return {4, 6};
     if (W <= 128 && H <= 32) return {8, 4};
+    if (W <= 128 && H <= 48) return {8, 6};  // a plane that fits ONE region: one workgroup, one launch, no ghost cells
     if ((size_t)H * W >= (size_t)300 * 1000) return {12, 4};
     return {8, 4};
 }

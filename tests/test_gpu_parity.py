@@ -351,6 +351,19 @@ def test_sor_exact_more_tasks_than_the_chip_keeps_resident(gpu, oracle):
     assert np.array_equal(du, eu) and np.array_equal(dv, ev)
 
 
+def test_sor_plan_reports_how_a_solve_is_issued(gpu):
+    """papof_sor_plan (bench.py prices the roofline's per-launch figures with it): the exact-order kernels run a solve as
+    ONE launch unless it has more tasks than the chip keeps resident; the blocked red-black kernel runs 10 half-sweeps
+    per launch (whole sweeps per launch), a plane that fits one region in one launch; Jacobi counts sweeps."""
+    assert gpu.sor_plan(1080, 1920, 30, 0) == (1, 2)      # level 0: two sweeps per wave (k_sor_fused)
+    assert gpu.sor_plan(341, 607, 30, 0) == (1, 1)
+    assert gpu.sor_plan(1080, 64, 200, 0)[0] > 1           # 4200 tasks > 8 per CU: consecutive launches
+    assert gpu.sor_plan(1080, 1920, 30, 1) == (6, 10)
+    assert gpu.sor_plan(1080, 1920, 33, 1) == (7, 10)      # 33 sweeps: 5 + 5 + 5 + 5 + 5 + 4 + 4
+    assert gpu.sor_plan(42, 75, 42, 1) == (1, 84)          # one region: one launch, no ghost cells
+    assert gpu.sor_plan(270, 480, 30, 2) == (5, 6)
+
+
 def test_full_size_properties(gpu):
     """Size-independent properties at BASELINE.json's full 1920x1080 size."""
     a, b = cases.load_pair("1920")
