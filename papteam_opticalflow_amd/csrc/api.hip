@@ -257,9 +257,12 @@ int bicubic_planes(papof_handle* h, const double* f2, int H, int W, int fc, Solv
 // OpticalFlow::SmoothFlowSOR (src/OpticalFlow.cpp:238-536) for one level, everything on the device.
 // genInImageMask (:278) and estLaplacianNoise (:530) do not influence the results (the mask
 // is never read; the noise estimate only feeds a `< 1e-20` guard) and are not executed.
-int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* warp, double* u, double* v, int H,
-                int W, int fc, double alpha, int n_outer, int n_inner, int n_sor, double omega, int mode,
-                SolveBuffers& B, PhaseClock& clk, const double* im1s_ready = nullptr) {
+// (u, v) and (ua, va) are two pairs of planes: every outer iteration writes the updated flow into the other pair (its
+// update kernel also reads the neighbours' old values, for phi) and the references are swapped -- on return `u`, `v` name
+// the planes that hold the result.
+int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* warp, double*& u, double*& v, double*& ua,
+                double*& va, int H, int W, int fc, double alpha, int n_outer, int n_inner, int n_sor, double omega,
+                int mode, SolveBuffers& B, PhaseClock& clk, const double* im1s_ready = nullptr) {
     const Taps g = smooth5_taps();
     const double* im1s = im1s_ready;  // smoothed frame 1: constant within the level (prepared ahead by flow_device)
     if (!im1s) {
@@ -275,8 +278,12 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
         // psi at imdt + imdx*du + imdy*dv with the increment of the previous solve; the solve itself restarts at 0
         for (int hh = 0; hh < n_inner; hh++) {
             const SorPlanes* prev = hh == 0 ? nullptr : &B.sp;
-            clk.phase(PAPOF_T_PHASE2_DERIVATIVES);
-            PAPOF_TRY(compute_phi(h, u, v, prev, B.phi, H, W));
+            // phi (Phase2): of the level's initial flow, and inside further inner iterations (at u + du), by its own kernel;
+            // for every later outer iteration the previous iteration's update kernel has written it already
+            if (count == 0 || hh > 0) {
+                clk.phase(PAPOF_T_PHASE2_DERIVATIVES);
+                PAPOF_TRY(compute_phi(h, u, v, prev, B.phi, H, W));
+            }
             // psi (Phase3, src/OpticalFlow.cpp:377-406) and the linear system (Phase4, :414-448) are ONE kernel here: its
             // time is recorded under Phase4 and apportioned between the two timers when they are collected (kPsiShare)
             clk.phase(PAPOF_T_PHASE4_LINEARSYSTEM);
@@ -295,12 +302,12 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
             PAPOF_TRY(rc_solve);
         }
         // Phase6 (opened by the solver's end mark): u += du, v += dv and the re-warp of frame 2 (:513-521)
-        if (!B.bgx) {
-            PAPOF_TRY(update_and_warp(h, B.sp, u, v, f1, f2, warp, H, W, fc));
-        } else {  // interpolation == Bicubic: warpImageBicubicRef + threshold() on the feature planes
-            PAPOF_TRY(update_and_warp(h, B.sp, u, v, f1, f2, warp, H, W, fc, false));
+        double* const phi_next = count + 1 < n_outer ? B.phi : nullptr;  // the next outer iteration's phi, fused in
+        PAPOF_TRY(update_warp_phi(h, B.sp, u, v, ua, va, f1, f2, warp, phi_next, H, W, fc, !B.bgx));
+        std::swap(u, ua);
+        std::swap(v, va);
+        if (B.bgx)  // interpolation == Bicubic: warpImageBicubicRef + threshold() on the feature planes
             PAPOF_TRY(bicubic_warp(h, f1, f2, B.bgx, B.bgy, B.bgxy, u, v, warp, H, W, fc, nullptr, true, true));
-        }
         if (B.gm) PAPOF_TRY(est_gaussian_mixture(h, f1, warp, H, W, fc, B.gm, B.gm_scratch));  // :524-528
     }
     clk.phase(-1);
@@ -638,7 +645,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
             }
             PAPOF_TRY(sor_bind(h, B.sp, lh, lw, P.n_sor + k * P.n_sor_per_level));
             PAPOF_TRY(sor_reset_planes(h, B.sp));
-            PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, lh, lw, fc, P.alpha, P.n_outer + k * P.n_outer_per_level,
+            PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, u2, v2, lh, lw, fc, P.alpha, P.n_outer + k * P.n_outer_per_level,
                                   P.n_inner, P.n_sor + k * P.n_sor_per_level, P.omega, P.sor_mode, B, clk, S1[k]));
             pw = lw;
             ph = lh;
@@ -1484,6 +1491,8 @@ int papof_stage_smoothflow_ex(papof_handle* h, const double* im1, const double* 
     double* w = S.up_planar(warp, height, width, c);
     double* du = S.up_planar(u, height, width, 1);
     double* dv = S.up_planar(v, height, width, 1);
+    double* du_alt = S.dev((size_t)height * width);
+    double* dv_alt = S.dev((size_t)height * width);
     PAPOF_TRY(S.rc);
     SolveBuffers B;
     PAPOF_TRY(alloc_solve_buffers(h->arena, height, width, c, sor_mode, n_sor, B));
@@ -1493,8 +1502,8 @@ int papof_stage_smoothflow_ex(papof_handle* h, const double* im1, const double* 
     PAPOF_TRY(sor_bind(h, B.sp, height, width, n_sor));
     PAPOF_TRY(sor_reset_planes(h, B.sp));
     PhaseClock clk{h, false};
-    PAPOF_TRY(smooth_flow(h, f1, f2, w, du, dv, height, width, c, alpha, n_outer, n_inner, n_sor, omega, sor_mode, B,
-                          clk));
+    PAPOF_TRY(smooth_flow(h, f1, f2, w, du, dv, du_alt, dv_alt, height, width, c, alpha, n_outer, n_inner, n_sor, omega,
+                          sor_mode, B, clk));
     PAPOF_TRY(S.down_planar(w, warp, height, width, c));
     PAPOF_TRY(S.down_planar(du, u, height, width, 1));
     PAPOF_TRY(S.down_planar(dv, v, height, width, 1));

@@ -321,6 +321,9 @@ int bicubic_warp(papof_handle* h, const double* im1, const double* im2, const do
 int flow_quantize16(papof_handle* h, const double* vx, const double* vy, unsigned short* q, size_t n);
 int flow_dequantize16(papof_handle* h, const unsigned short* q, double* vx, double* vy, size_t n);
 int flow_to_bgr(papof_handle* h, const double* vx, const double* vy, size_t n, double* partial, unsigned char* bgr);
+int update_warp_phi(papof_handle* h, const SorPlanes& sp, const double* u, const double* v, double* u_out, double* v_out,
+                    const double* im1, const double* im2, double* warp, double* phi_out, int H, int W, int planes,
+                    bool do_warp = true);
 int update_flow(papof_handle* h, const SorPlanes& sp, double* u, double* v, int H, int W, const Rect& r);
 int sor_prep(papof_handle* h, const double* phi, const double* imdxy, const double* imdx2, const double* imdy2,
              const double* rhs1, const double* rhs2, int H, int W, double alpha, double omega, const SorPlanes& out);

@@ -644,6 +644,65 @@ __global__ void k_update_warp(const double* __restrict__ sdu, const double* __re
     if (do_warp) warp_pixel(im1, im2, warp, fu, fv, i, j, H, W, planes);
 }
 
+// One-GPU path of Phase 6 with the NEXT outer iteration's Phase 2 folded in: u_out = u + du, v_out = v + dv go to
+// another pair of planes (the neighbours' old values are still read below), the re-warp uses the new flow, and -- when
+// phi_out is given -- phi = 0.5 / sqrt(ux^2 + uy^2 + vx^2 + vy^2 + eps) of the NEW flow (src/OpticalFlow.cpp:295-331, the
+// expressions of k_phi) is written as well: u_new(i, j+1) = u(i, j+1) + du(i, j+1) is the same addition its own thread
+// performs, hence the same bits.  Saves one launch and one pass over (u, v) per outer iteration.
+template <bool SKEW>
+__global__ void k_update_warp_phi(const double* __restrict__ sdu, const double* __restrict__ sdv, SkewIdx sk,
+                                  const double* __restrict__ u, const double* __restrict__ v,
+                                  double* __restrict__ u_out, double* __restrict__ v_out,
+                                  const double* __restrict__ im1, const double* __restrict__ im2,
+                                  double* __restrict__ warp, double* __restrict__ phi_out, int H, int W, int planes,
+                                  int do_warp, unsigned long long* stamp) {
+    stamp_now(stamp);
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t o = (size_t)i * W + j;
+    const auto inc = [&](int ii, int jj, double& a, double& b) {
+        if (SKEW) {
+            const double2s c = reinterpret_cast<const double2s*>(sdu)[dudv_cell(ii, jj, sk)];
+            a = c.x;
+            b = c.y;
+        } else {
+            a = sdu[(size_t)ii * W + jj];
+            b = sdv[(size_t)ii * W + jj];
+        }
+    };
+    double a, b;
+    inc(i, j, a, b);
+    double fu = u[o], fv = v[o];
+    fu += a;
+    fv += b;
+    u_out[o] = fu;
+    v_out[o] = fv;
+    if (phi_out != nullptr) {
+        double ur = 0.0, vr = 0.0, ud = 0.0, vd = 0.0;
+        if (j < W - 1) {
+            inc(i, j + 1, a, b);
+            ur = u[o + 1];
+            vr = v[o + 1];
+            ur += a;
+            vr += b;
+        }
+        if (i < H - 1) {
+            inc(i + 1, j, a, b);
+            ud = u[o + W];
+            vd = v[o + W];
+            ud += a;
+            vd += b;
+        }
+        const double ux = j < W - 1 ? ur - fu : 0.0;
+        const double uy = i < H - 1 ? ud - fu : 0.0;
+        const double vx = j < W - 1 ? vr - fv : 0.0;
+        const double vy = i < H - 1 ? vd - fv : 0.0;
+        const double t = ux * ux + uy * uy + vx * vx + vy * vy;
+        phi_out[o] = 0.5 / sqrt(t + 0.001 * 0.001);
+    }
+    if (do_warp) warp_pixel(im1, im2, warp, fu, fv, i, j, H, W, planes);
+}
+
 // Exact-order solver layout: (du, dv) read straight from the paired skewed plane (16 bytes per thread; an LDS-staged
 // transposition of the tile was measured slower: the kernel is bound by the 4-tap x C-plane gather of the warp).
 __global__ void k_update_warp_skew(const double2s* __restrict__ pd, double* __restrict__ u, double* __restrict__ v,
@@ -1019,6 +1078,21 @@ int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, 
         hipLaunchKernelGGL(k_update_warp, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, u, v, im1, im2, warp,
                            H, W, planes, Rect{0, 0, W, H}, do_warp ? 1 : 0, take_stamp(h));
     }
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int update_warp_phi(papof_handle* h, const SorPlanes& sp, const double* u, const double* v, double* u_out, double* v_out,
+                    const double* im1, const double* im2, double* warp, double* phi_out, int H, int W, int planes,
+                    bool do_warp) {
+    if (u == u_out || v == v_out) return PAPOF_EINVAL;
+    if (sp.skew)
+        hipLaunchKernelGGL(k_update_warp_phi<true>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, skew_idx(sp),
+                           u, v, u_out, v_out, im1, im2, warp, phi_out, H, W, planes, do_warp ? 1 : 0, take_stamp(h));
+    else
+        hipLaunchKernelGGL(k_update_warp_phi<false>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv,
+                           SkewIdx{0, 0, 0, 0, 0, 0, 0, 0, 0}, u, v, u_out, v_out, im1, im2, warp, phi_out, H, W, planes,
+                           do_warp ? 1 : 0, take_stamp(h));
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
