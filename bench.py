@@ -279,7 +279,9 @@ def main():
         a, b, data_desc = load_frames(args.res)
         h, w, c = a.shape
         P = default_params(n_outer=sched[0], n_outer_per_level=sched[1], n_sor=sched[2], n_sor_per_level=sched[3],
-                           sor_mode=mode, omega=1.8 if mode != 2 else 1.0, phase_timing=0)
+                           sor_mode=mode, omega=1.8 if mode != 2 else 1.0, phase_timing=2)  # total + SOR kernels only
+        P_call = default_params(n_outer=sched[0], n_outer_per_level=sched[1], n_sor=sched[2], n_sor_per_level=sched[3],
+                                sor_mode=mode, omega=1.8 if mode != 2 else 1.0, phase_timing=0)  # the drop-in's default
         d1, d2 = gpu.dev_alloc(a.nbytes), gpu.dev_alloc(b.nbytes)
         dvx, dvy, dwp = gpu.dev_alloc(h * w * 8), gpu.dev_alloc(h * w * 8), gpu.dev_alloc(a.nbytes)
         gpu.dev_upload(d1, a)  # inputs resident in HBM before the timed region
@@ -381,7 +383,8 @@ def main():
                                    "%s-order SOR" % (w, h, args.levels, args.schedule, sched[0], sched[1], sched[2],
                                                      sched[3], args.mode),
                        "value_is": "device-resident: both frames and the results already / still in HBM "
-                                   "(papof_flow_device); the drop-in call with host buffers is value_call_inclusive",
+                                   "(papof_flow_device, timers: total + SOR kernels); the drop-in call with host buffers "
+                                   "and all ten timers is value_call_inclusive",
                        "pairs_in_flight_per_gpu": args.pairs,
                        "parallelism": "replicas: one independent frame pair per GPU" if world > 1 else "1 GPU"},
             "max_abs_duv_vs_reference": parity,
@@ -424,10 +427,10 @@ def main():
                 g2.close()
         if world == 1 and not simulate:
             # the drop-in entry point's view (host buffers in and out, pageable numpy arrays): NOT `value`
-            gpu.coarse2fine_flow(a, b, args.levels, P)
+            gpu.coarse2fine_flow(a, b, args.levels, P_call)
             th = time.perf_counter()
             for _ in range(3):
-                gpu.coarse2fine_flow(a, b, args.levels, P)
+                gpu.coarse2fine_flow(a, b, args.levels, P_call)
             out["pcie_inclusive_ms_per_pair"] = round((time.perf_counter() - th) / 3 * 1e3, 3)
             # BASELINE.md's definition of the metric on the caller's clock: H*W / wall seconds of ONE
             # coarse2fine_flow(im1, im2, levels) call, float64 numpy frames in, float64 results out (both PCIe transfers)

@@ -79,7 +79,10 @@ typedef struct papof_params {
                               0: flow-independent work (pyramids = Construction, features = Allocation, derivative planes of
                                  the final warp = PostProcessing) runs on a second stream BESIDE the solver phases, so the
                                  ten values overlap in time and add up to more than the total;
-                              1: everything on one stream: phases do not overlap (slower by the lost overlap).
+                              1: everything on one stream: phases do not overlap (slower by the lost overlap);
+                              2: as 0, but only "Total C++ Execution" and "Phase5_SOR" are measured (the other eight read 0):
+                                 no phase stamps at all -- what bench.py's device-resident headline runs with, as in round 1
+                                 (the stamps cost <= 0.1 ms per 1080p call).
                               Phase5_SOR is the solver kernels' own duration in both cases.  Phase3_PsiData and
                               Phase4_LinearSystem are ONE fused kernel here: its time is apportioned 30 : 70.          */
     int interpolation;     /* PAPOF_INTERP_*  (0 = the reference's default)                                          */

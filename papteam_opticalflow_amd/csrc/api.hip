@@ -452,7 +452,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     PhaseClock clk{h, !in_capture};
     PhaseClock pclk{h, !in_capture};
     PhaseClock total{h, !in_capture};
-    clk.only_sor = pclk.only_sor = !h->phase_events && P.phase_timing == 0;
+    clk.only_sor = pclk.only_sor = (!h->phase_events && P.phase_timing == 0) || P.phase_timing == 2;
     clk.stamps = true;  // the main stream's phase boundaries are in-kernel stamps, not events (flow_internal.h)
     h->stamps_used = 0;
     h->next_stamp = nullptr;
@@ -535,7 +535,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         }
     }
 
-    const bool overlap = h->overlap_prep && P.phase_timing == 0 && h->prep_stream != nullptr;
+    const bool overlap = h->overlap_prep && P.phase_timing != 1 && h->prep_stream != nullptr;
     hipStream_t const main_stream = h->stream, prep = overlap ? h->prep_stream : h->stream;
     while (h->sync_events.size() < (size_t)levels + 2) {
         hipEvent_t e;
