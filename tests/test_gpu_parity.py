@@ -341,6 +341,30 @@ def test_sor_blocked_kernels_match_oracle_at_size(gpu, oracle, mode, omega, h, w
     assert np.array_equal(du, eu) and np.array_equal(dv, ev), (mode, h, w, n_sor, np.abs(du - eu).max())
 
 
+@pytest.mark.parametrize("knobs", [{}, {"PAPOF_RB_SHAPE": "1"}, {"PAPOF_RB_SHAPE": "3", "PAPOF_RB_DEPTH": "5"},
+                                   {"PAPOF_RB_SHAPE": "4", "PAPOF_RB_DEPTH": "7"}, {"PAPOF_RB_SHAPE": "5", "PAPOF_RB_DEPTH": "14"},
+                                   {"PAPOF_RB_NAIVE": "1"}])
+def test_sor_blocked_random_shapes_and_every_region_shape(oracle, knobs, monkeypatch):
+    """Seeded random plane sizes (odd and even widths, planes smaller and larger than a region, 1 .. 12 sweeps) through
+    every region shape / depth the blocked solver has (odd depths force the shifted, even-aligned regions), and through
+    the one-launch-per-half-sweep kernels kept as a cross-check: all must give the oracle's bits in the same mode."""
+    from papteam_opticalflow_amd import Papof
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    g = Papof(0)
+    try:
+        rng = np.random.default_rng(2026)
+        for _ in range(14):
+            h, w, n_sor = int(rng.integers(1, 220)), int(rng.integers(1, 420)), int(rng.integers(1, 13))
+            planes = _sor_planes(h, w, 17 * h + w)
+            for mode, omega in ((1, 1.8), (2, 1.0)):
+                du, dv = g.sor(*planes, n_sor, omega=omega, mode=mode)
+                eu, ev = oracle.sor(*planes, n_sor, omega=omega, mode=mode)
+                assert np.array_equal(du, eu) and np.array_equal(dv, ev), (knobs, mode, h, w, n_sor)
+    finally:
+        g.close()
+
+
 def test_sor_exact_more_tasks_than_the_chip_keeps_resident(gpu, oracle):
     """Forward progress beyond co-residency: 1080 rows x 200 sweeps = 21 bands x 200 = 4200 one-wave tasks, more than the
     3072 waves the chip holds at the kernel's occupancy.  sor_solve issues such a solve as consecutive launches of at
