@@ -155,7 +155,7 @@ def flow_collection(frames, pyramidLevels, in_flight=4, device=None, on_pair=Non
                 for i in range(bounds[s], bounds[s + 1] + 1):
                     if on_pair is not None and out is None and i > bounds[s]:
                         h, w, c = np.shape(frames[i])
-                        out = (np.zeros((h, w)), np.zeros((h, w)), np.zeros((h, w, c)))
+                        out = (capi.result_array((h, w)), capi.result_array((h, w)), capi.result_array((h, w, c)))
                     r = seq.push(frames[i], out)
                     if i > bounds[s]:
                         if on_pair is not None:

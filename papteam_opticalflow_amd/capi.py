@@ -300,7 +300,7 @@ class Papof:
                 if a_.dtype != np.float64 or a_.shape != shp or not a_.flags["C_CONTIGUOUS"]:
                     raise ValueError("out arrays must be C-contiguous float64 of shapes (h,w), (h,w), (h,w,c)")
         else:
-            vx, vy, wi = np.zeros((h, w)), np.zeros((h, w)), np.zeros((h, w, c))
+            vx, vy, wi = result_array((h, w)), result_array((h, w)), result_array((h, w, c))
         pp = ctypes.byref(params) if params is not None else None
         have = c_int(0)
         if u8:
