@@ -183,6 +183,7 @@ def test_pinned_result_arrays_are_recycled_and_hold_the_same_results(monkeypatch
         assert vx.flags.writeable and vx.dtype == np.float64 and vx.flags.c_contiguous
         vx += 1.0  # an ordinary array
         addr = vx.ctypes.data
+        gc.collect()  # whatever earlier tests left behind goes now, not between the two readings below
         live = capi._pinned_live[0]
         assert live >= vx.nbytes + vy.nbytes + wi.nbytes
         view = vx[10:20]  # a view keeps the block alive
