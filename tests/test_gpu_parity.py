@@ -329,6 +329,23 @@ def test_config3_960x540_redblack_matches_oracle(gpu, oracle):
     print("   distance of red-black to the reference order (subsample): %.3e" % d)
 
 
+def test_config4_1920x1080_redblack_matches_oracle(gpu, oracle):
+    """BASELINE.json configs[3] at its full size with the kernel north_star describes (red-black SOR, LDS-staged halos):
+    1920x1080 pair, 5 levels, 3 outer / 30 SOR, end to end against the oracle run in the same mode (~7 s of one host
+    core).  The exact-order run of the same configuration is compared with the reference's golden in
+    test_end_to_end_matches_reference_golden[cfg4_1920_L5]."""
+    from papteam_opticalflow_amd import default_params
+    a, b = cases.load_pair("1920")
+    kw = dict(n_outer=3, n_outer_per_level=0, n_sor=30, n_sor_per_level=0)
+    got = gpu.coarse2fine_flow(a, b, 5, default_params(sor_mode=1, **kw))[:3]
+    p = oracle.default_params()
+    for k, v in dict(kw, sor_mode=1).items():
+        setattr(p, k, v)
+    want = oracle.coarse2fine_flow(a, b, 5, p)[:3]
+    for name, g, w_ in zip(("vx", "vy", "warpI2"), got, want):
+        _cmp("config4 1920x1080 red-black %s" % name, g, w_, TOL_SOLVE)
+
+
 @pytest.mark.parametrize("mode,omega", [(1, 1.8), (2, 1.0)])
 @pytest.mark.parametrize("h,w,n_sor", [(1080, 1920, 30), (540, 960, 33), (341, 607, 42), (270, 480, 7), (129, 3, 2),
                                         (3, 300, 5), (49, 127, 11), (48, 128, 10), (97, 257, 1)])
