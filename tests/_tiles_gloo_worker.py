@@ -2,10 +2,13 @@
 
 Rehearses the N>1 protocol of the tiled solver (csrc/tiles.hip) with real inter-process messages (torch.distributed,
 gloo): the tile rectangles and the owner -> needer message plan come from the PRODUCT library's host functions
-(papof_tiles_rect / papof_tiles_halo_message -- no GPU needed), the ghost-zone schedule (one (du, dv) exchange per S
-half-sweeps, half-sweep m on the tile grown by S-1-m) is the one tiles.hip runs, and the red-black cell update is
-restated in numpy with the reference's operation order (src/OpticalFlow.cpp:468-504).  Rank 0 gathers the tiles and
-compares the result bit for bit with the CPU oracle's red-black solve of the whole plane.
+(papof_tiles_rect / papof_tiles_halo_message -- no GPU needed); the solve follows tiles.hip launch for launch -- a
+period of S half-sweeps between two (du, dv) exchanges is one or more launches of the temporally blocked solver (the
+numpy model of k_sor_blocked, tests/sim_sor_blocked.py), each of depth g delivering the tile grown by what is left of
+the period and reading that rectangle grown by g, alternating between two pairs of planes; an exchange fills the
+ghost ring of the pair the next launch reads.  Rank 0 gathers the tiles and compares the result bit for bit with the
+CPU oracle's red-black solve of the whole plane.  (`halfsweep` below is the round-1 schedule, one half-sweep on the
+tile grown by S-1-m at a time: kept as an independent restatement and run as a cross-check.)
 """
 import os
 import sys
@@ -103,14 +106,30 @@ def main():
     import sim_sor_wave as sim
     a1, a2 = sim.sor_coefficients(phi, x2, y2, alpha, omega)
     T = capi.tiles_rect(w, h, rows, cols, rank)
-    du, dv = np.zeros((h, w)), np.zeros((h, w))
+    P = (phi, xy, a1, a2, b1, b2)
     n_half, n_ex = 2 * n_sor, 0
-    for hs in range(n_half):
-        m = hs % halo
-        halfsweep((phi, xy, a1, a2, b1, b2), du, dv, grow(T, halo - 1 - m, w, h), hs & 1, alpha, omega, h, w)
-        if m == halo - 1 and hs != n_half - 1:
-            exchange((du, dv), w, h, rows, cols, halo, rank, n)
+    import sim_sor_blocked as blk
+    gmax = int(sys.argv[7]) if len(sys.argv) > 7 else 10  # depth cap of one launch (the region allows 15 at 32 rows)
+    su = sv = None
+    hs = 0
+    while hs < n_half:  # tiles.hip, round 2
+        s = min(halo, n_half - hs)
+        done = 0
+        while done < s:
+            g = min(gmax, s - done)
+            su, sv = blk._launch(P, su, sv, h, w, g, hs + done, 1, 32, alpha, omega, out=grow(T, s - done - g, w, h))
+            done += g
+        hs += s
+        if hs < n_half:
+            exchange((su, sv), w, h, rows, cols, halo, rank, n)
             n_ex += 1
+    du, dv = su, sv
+    # cross-check against the independent half-sweep restatement above where no messages are involved (one rank)
+    if n == 1:
+        cu, cv = np.zeros((h, w)), np.zeros((h, w))
+        for k in range(n_half):
+            halfsweep(P, cu, cv, (0, 0, w, h), k & 1, alpha, omega, h, w)
+        assert np.array_equal(cu, du) and np.array_equal(cv, dv)
     # gather the tiles on rank 0 (need = whole plane there: a halo as large as the plane)
     mine = np.ascontiguousarray(np.stack([du[T[1]:T[3], T[0]:T[2]], dv[T[1]:T[3], T[0]:T[2]]]))
     if rank == 0:

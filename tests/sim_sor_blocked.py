@@ -32,19 +32,24 @@ def _cell_update(w_l, w_u, pc, xy, a1, a2, b1, b2, own_u, own_v, L, R, U, D, nal
     return nu, nv
 
 
-def _launch(planes, su, sv, H, W, g, hs0, mode, RH, alpha, omega):
-    """one launch over the whole plane: returns the new (du, dv) planes"""
+def _launch(planes, su, sv, H, W, g, hs0, mode, RH, alpha, omega, out=None):
+    """one launch that delivers the rectangle `out` = (x0, y0, x1, y1) (default: the whole plane; a tile grown by its
+    remaining ghost depth in the multi-GPU path, csrc/tiles.hip): returns the new (du, dv) planes, NaN outside `out`"""
     phi, xy, a1, a2, b1, b2 = planes
     nalpha, om1 = -alpha, 1 - omega
-    span_x, span_y = W <= RW, H <= RH
-    cw = W if span_x else RW - 2 * g - 2 * ((0 - g) & 1)
+    ox0_, oy0_, ox1_, oy1_ = out if out is not None else (0, 0, W, H)
+    du, dv = np.full((H, W), np.nan), np.full((H, W), np.nan)
+    if ox1_ <= ox0_ or oy1_ <= oy0_:
+        return du, dv
+    span_x = ox0_ == 0 and ox1_ == W and W <= RW
+    span_y = oy0_ == 0 and oy1_ == H and H <= RH
+    shift = 0 if span_x else ((ox0_ - g) & 1)
+    cw = W if span_x else RW - 2 * g - 2 * shift
     ch = H if span_y else RH - 2 * g
     assert cw >= 1 and ch >= 1
-    shift = 0 if span_x else ((0 - g) & 1)
-    du, dv = np.full((H, W), np.nan), np.full((H, W), np.nan)
-    for cy0 in range(0, H, ch):
-        for cx0 in range(0, W, cw):
-            cx1, cy1 = min(cx0 + cw, W), min(cy0 + ch, H)
+    for cy0 in range(oy0_, oy1_, ch):
+        for cx0 in range(ox0_, ox1_, cw):
+            cx1, cy1 = min(cx0 + cw, ox1_), min(cy0 + ch, oy1_)
             rx0, rx1 = max(0, cx0 - g - shift), min(W, cx1 + g)
             ry0, ry1 = max(0, cy0 - g), min(H, cy1 + g)
             assert rx1 - rx0 <= RW and ry1 - ry0 <= RH and rx0 % 2 == 0
@@ -83,7 +88,7 @@ def _launch(planes, su, sv, H, W, g, hs0, mode, RH, alpha, omega):
                 cv[frame] = nv[frame]
             du[cy0:cy1, cx0:cx1] = u[1 + cy0 - ry0:1 + cy1 - ry0, 1 + cx0 - rx0:1 + cx1 - rx0]
             dv[cy0:cy1, cx0:cx1] = v[1 + cy0 - ry0:1 + cy1 - ry0, 1 + cx0 - rx0:1 + cx1 - rx0]
-    assert not np.isnan(du).any()
+    assert not np.isnan(du[oy0_:oy1_, ox0_:ox1_]).any()
     return du, dv
 
 

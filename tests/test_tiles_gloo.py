@@ -22,13 +22,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("h,w,n_sor,halo,rows,cols", [(45, 64, 7, 4, 1, 2), (50, 37, 5, 3, 2, 1), (61, 70, 6, 5, 2, 2),
-                                                       (40, 40, 4, 1, 1, 2)])
-def test_ghost_zone_halo_exchange_over_gloo(h, w, n_sor, halo, rows, cols):
+@pytest.mark.parametrize("h,w,n_sor,halo,rows,cols,gmax", [(45, 64, 7, 4, 1, 2, 10), (50, 37, 5, 3, 2, 1, 10),
+                                                            (61, 70, 6, 5, 2, 2, 10), (40, 40, 4, 1, 1, 2, 10),
+                                                            (70, 300, 9, 7, 2, 2, 5), (33, 21, 3, 6, 1, 1, 4)])
+def test_ghost_zone_halo_exchange_over_gloo(h, w, n_sor, halo, rows, cols, gmax):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(rows * cols),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "_tiles_gloo_worker.py")] + [str(x) for x in (h, w, n_sor, halo, rows, cols)]
+           os.path.join(ROOT, "tests", "_tiles_gloo_worker.py")] + [str(x) for x in (h, w, n_sor, halo, rows, cols, gmax)]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     m = re.search(r"TILES_GLOO ok=(\d) exchanges=(\d+)", out.stdout)
