@@ -349,6 +349,8 @@ def main():
             nl, dp = gpu.sor_plan(lh, lw, sched[2] + k * sched[3], mode) if gpu is not None else (1, 1)
             launches += (sched[0] + k * sched[1]) * nl
             depths.append(dp)
+        if gpu is not None and mode == 0 and args.pairs == 1:  # what the last step really launched (levels solved as strips
+            launches = gpu.last_sor_stats()[0] or launches      # of bands issue one launch per strip and solve)
         sor_step = sor_sec / args.steps
         achieved = updates * BYTES_PER_UPDATE / 1e9 / sor_step if sor_step > 0 else 0.0
         traffic = None

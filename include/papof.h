@@ -311,6 +311,27 @@ int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_m
  * wave; red-black: HALF-sweeps per launch of the LDS-tiled, temporally blocked kernel; Jacobi: sweeps per launch). */
 int papof_sor_plan(papof_handle* h, int height, int width, int n_sor, int sor_mode, int* launches, int* depth);
 
+/* Measurement aid for bench.py: what the LAST papof_flow* / papof_seq_push* call on this handle launched -- exact-order
+ * solver kernels in all (a level solved as strips of bands issues one launch per strip and solve), and how many
+ * seconds of the reported Phase5_SOR are launches on the strip streams, i.e. ran beside the main stream's time line. */
+int papof_last_sor_stats(papof_handle* h, int* launches, double* strip_streams_sec);
+
+/* Test aid: the strip schedule (api.hip: smooth_flow_strips) a level of height x width with `n_sor` sweeps and
+ * `n_outer` outer iterations gets on this handle.  *strips = S (1: the level is not cut).  out, if not NULL, receives
+ * for n = 0 .. n_outer and s = 0 .. S five ints each -- first band, first row of the update / phi / smoothing / assembly
+ * stage of strip s before solve n -- (n_outer + 1) * (S + 1) * 5 ints (cap = ints available); *band_rows, *koff: rows
+ * per band and climb of the bands up to the last sweep of the bound solver layout. */
+int papof_strip_plan(papof_handle* h, int height, int width, int n_sor, int n_outer, int want_strips, int* strips,
+                     int* out, int cap, int* band_rows, int* koff, int* bands);
+
+/* Test aid: one exact-order solve of `n_sor` sweeps on synthetic height x width planes (the micro-benchmark's), once
+ * whole and `reps` times as two strips of solver bands -- bands < split_band on a second stream, the rest `delay_us`
+ * microseconds later on the handle's stream (sor.hip: sor_solve_bands).  *mismatches = 16-byte cells of the solver's
+ * (du, dv) planes, intermediate sweeps included, that differ from the whole solve's (0 expected); *bands = bands of the
+ * layout.  PAPOF_EINVAL when this layout cannot be solved in strips (<= 8 bands, < 3 sweeps, split out of range). */
+int papof_test_sor_strips(papof_handle* h, int height, int width, int n_sor, int split_band, int reps, int delay_us,
+                          long long* mismatches, int* bands);
+
 #ifdef __cplusplus
 }
 #endif

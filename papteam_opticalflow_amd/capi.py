@@ -47,7 +47,7 @@ SYMBOLS = [
     "papof_seq_push", "papof_seq_push_u8", "papof_seq_push_device", "papof_tiles_grid", "papof_tiles_rect",
     "papof_tiles_halo_message", "papof_tiles_unique_id", "papof_tiles_create", "papof_tiles_create_local",
     "papof_tiles_flow_device", "papof_tiles_stats", "papof_tiles_destroy", "papof_flow_quantize16",
-    "papof_flow_dequantize16", "papof_flow_to_bgr", "papof_set_graph_mode", "papof_sor_plan",
+    "papof_flow_dequantize16", "papof_flow_to_bgr", "papof_set_graph_mode", "papof_sor_plan", "papof_last_sor_stats", "papof_strip_plan", "papof_test_sor_strips",
     "papof_pyramid_levels_for_min_width", "papof_stage_smoothflow_ex", "papof_stage_est_gaussian_mixture",
     "papof_stage_bicubic_warp_ex", "papof_tiles_comm_info", "papof_host_alloc", "papof_host_free",
 ]
@@ -136,6 +136,12 @@ def load():
     L.papof_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(c_void_p)]
     L.papof_host_free.argtypes = [c_void_p]
     L.papof_sor_plan.argtypes = [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    L.papof_last_sor_stats.argtypes = [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]
+    L.papof_test_sor_strips.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(c_int)]
+    L.papof_strip_plan.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int),
+                                   ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                   ctypes.POINTER(c_int)]
     _lib = L
     return L
 
@@ -529,6 +535,32 @@ class Papof:
         nl, d = c_int(0), c_int(0)
         _chk(self.L.papof_sor_plan(self.h, h, w, n_sor, mode, ctypes.byref(nl), ctypes.byref(d)), "papof_sor_plan")
         return nl.value, d.value
+
+    def last_sor_stats(self):
+        """(exact-order solver launches of the last flow call, seconds of Phase5_SOR that ran on the strip streams)"""
+        nl, sec = c_int(0), c_double(0)
+        _chk(self.L.papof_last_sor_stats(self.h, ctypes.byref(nl), ctypes.byref(sec)), "papof_last_sor_stats")
+        return nl.value, sec.value
+
+    def test_sor_strips(self, h, w, n_sor, split_band, reps=3, delay_us=0):
+        """(mismatching cells of a solve cut into two strips vs the whole solve, bands of the layout)"""
+        mm, nb = ctypes.c_longlong(0), c_int(0)
+        _chk(self.L.papof_test_sor_strips(self.h, h, w, n_sor, split_band, reps, delay_us, ctypes.byref(mm),
+                                          ctypes.byref(nb)), "papof_test_sor_strips")
+        return mm.value, nb.value
+
+    def strip_plan(self, h, w, n_sor, n_outer, want=0):
+        """strip schedule of one level: dict(S, band_rows, koff, bands, plan[n][s] = (band, rU, rP, rS, rA))"""
+        S, br, ko, nb = c_int(0), c_int(0), c_int(0), c_int(0)
+        cap = (n_outer + 1) * 5 * 5
+        buf = (c_int * cap)()
+        _chk(self.L.papof_strip_plan(self.h, h, w, n_sor, n_outer, want, ctypes.byref(S), buf, cap, ctypes.byref(br),
+                                     ctypes.byref(ko), ctypes.byref(nb)), "papof_strip_plan")
+        plan = []
+        if S.value > 1:
+            for n in range(n_outer + 1):
+                plan.append([tuple(buf[(n * (S.value + 1) + s) * 5 + i] for i in range(5)) for s in range(S.value + 1)])
+        return {"S": S.value, "band_rows": br.value, "koff": ko.value, "bands": nb.value, "plan": plan}
 
     def bench_sor(self, h, w, n_sor, mode=SOR_EXACT, reps=5, seed=2):
         ms = c_double(0)

@@ -262,7 +262,8 @@ int bicubic_planes(papof_handle* h, const double* f2, int H, int W, int fc, Solv
 // the planes that hold the result.
 int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* warp, double*& u, double*& v, double*& ua,
                 double*& va, int H, int W, int fc, double alpha, int n_outer, int n_inner, int n_sor, double omega,
-                int mode, SolveBuffers& B, PhaseClock& clk, const double* im1s_ready = nullptr) {
+                int mode, SolveBuffers& B, PhaseClock& clk, const double* im1s_ready = nullptr,
+                bool final_warp = true) {
     const Taps g = smooth5_taps();
     const double* im1s = im1s_ready;  // smoothed frame 1: constant within the level (prepared ahead by flow_device)
     if (!im1s) {
@@ -303,13 +304,202 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
         }
         // Phase6 (opened by the solver's end mark): u += du, v += dv and the re-warp of frame 2 (:513-521)
         double* const phi_next = count + 1 < n_outer ? B.phi : nullptr;  // the next outer iteration's phi, fused in
-        PAPOF_TRY(update_warp_phi(h, B.sp, u, v, ua, va, f1, f2, warp, phi_next, H, W, fc, !B.bgx));
+        // the re-warp after the LAST outer iteration of a level (:516) is read by nobody when the caller is flow_device (the
+        // next level warps anew, the result is the bicubic warp of the originals): final_warp = false skips it
+        const bool rewarp = !B.bgx && (final_warp || count + 1 < n_outer || B.gm);
+        PAPOF_TRY(update_warp_phi(h, B.sp, u, v, ua, va, f1, f2, warp, phi_next, H, W, fc, rewarp));
         std::swap(u, ua);
         std::swap(v, va);
         if (B.bgx)  // interpolation == Bicubic: warpImageBicubicRef + threshold() on the feature planes
             PAPOF_TRY(bicubic_warp(h, f1, f2, B.bgx, B.bgy, B.bgxy, u, v, warp, H, W, fc, nullptr, true, true));
         if (B.gm) PAPOF_TRY(est_gaussian_mixture(h, f1, warp, H, W, fc, B.gm, B.gm_scratch));  // :524-528
     }
+    clk.phase(-1);
+    return PAPOF_OK;
+}
+
+// =================================================================================================
+// STRIPS: one level of the exact-order path as S horizontal strips, each on its own stream.
+//
+// The exact-order solve is a wave front: band b starts one band hop (63 steps + a hand-off) after band b-1 and finishes
+// as much later, so the top of the plane is final long before the bottom, and the bottom bands of the NEXT solve could
+// not start before the top ones anyway.  A level is therefore cut into strips of solver bands; per outer iteration a
+// strip's chain is [update + warp + phi] -> [smoothing + blend] -> [assembly] -> [its bands of the solve], enqueued on
+// the strip's own stream.  The non-solver kernels of the upper strips run while the lower strips still solve, the
+// non-solver kernels of the lowest strip while the upper strips' next solve climbs its ramp: the same kernels, the
+// same operations per pixel, only the row ranges and the order in time differ (results are bit-identical).
+//
+// Row ranges.  A stage whose stencil reaches h rows further down than its output can only be run on rows whose inputs
+// are final, so the boundary between strip s-1 and strip s moves UP from stage to stage: with F = the first row whose
+// final (du, dv) lies in the first band of strip s, the update kernel of strip s-1 ends at F - 1 (phi of row i reads
+// row i + 1), the smoothing at F - 3 (5 x 5), the assembly at F - 5 (5-point derivatives of the blend), and the next
+// solve's boundary is the last band boundary at or above that row: boundaries move up by one band per solve (two when the
+// sweep count exceeds 57).  The strip below starts each stage where the strip above ended; what it reads across the
+// boundary is ordered by ONE event per iteration (recorded behind the upper strip's assembly).  Inside a solve the
+// strips meet through the solver's progress counters (sor.hip: sor_solve_bands).  Dependencies between stages point
+// from upper to lower strips only -- except the solver's write-after-read guard, which keeps an upper strip within two
+// sweeps per band of the strip below.
+// =================================================================================================
+struct LevelInit {  // how the level's initial flow and warp come about (src/OpticalFlow.cpp:801-816)
+    bool coarsest;          // u = v = 0 and warp = frame 2's features: already enqueued by the caller
+    const double *pu, *pv;  // else: the coarser level's flow, up-sampled and scaled per strip, then warped
+    int ph, pw;
+    double xr, yr, inv;
+};
+
+struct StripSchedule {
+    int S = 1, n_solves = 0;
+    // per solve n = 0 .. n_solves (n_solves = the final update) and boundary s = 0 .. S: first band of strip s in solve n
+    // (beta), first row of strip s in the update / warp stage (rU), phi (rP), smoothing (rS), assembly (rA)
+    std::vector<int> beta, rU, rP, rS, rA;
+    int idx(int n, int s) const { return n * (S + 1) + s; }
+};
+
+bool plan_strips(const papof_handle* h, const SorPlanes& sp, int H, int n_sor, int n_solves, int want,
+                 StripSchedule& out) {
+    if (want < 2 || n_solves < 1 || !sor_strips_supported(h, sp, n_sor)) return false;
+    const int BR = sp.sd.band_rows, koff = sp.sd.koff, nb = sp.sd.nb;
+    const int d = (koff + 5 + BR - 1) / BR;  // bands a boundary moves up per solve
+    for (int S = std::min(want, 4); S >= 2; --S) {
+        StripSchedule q;
+        q.S = S;
+        q.n_solves = n_solves;
+        const size_t cells = (size_t)(n_solves + 1) * (S + 1);
+        q.beta.assign(cells, 0);
+        q.rU.assign(cells, 0);
+        q.rP.assign(cells, 0);
+        q.rS.assign(cells, 0);
+        q.rA.assign(cells, 0);
+        // boundaries of the first solve: even shares of the bands, moved down by half of what they will climb
+        std::vector<int> b0(S + 1, 0);
+        b0[S] = nb;
+        int top = std::min(nb - 1, (H - 6) / BR);  // the last boundary's first stage (row BR * beta + 4) lies inside the plane
+        for (int s = S - 1; s >= 1; --s) {
+            b0[s] = std::min(top, (s * nb + S / 2) / S + d * (n_solves - 1) / 2);
+            top = b0[s] - 1;
+        }
+        bool ok = true;
+        for (int n = 0; n <= n_solves && ok; n++) {
+            for (int s = 0; s <= S; s++) {
+                const int i = q.idx(n, s);
+                if (s == 0 || s == S) {
+                    q.beta[i] = s == 0 ? 0 : nb;
+                    q.rU[i] = q.rP[i] = q.rS[i] = q.rA[i] = s == 0 ? 0 : H;
+                    continue;
+                }
+                if (n == 0) {
+                    q.beta[i] = b0[s];
+                    q.rU[i] = BR * b0[s] + 4;
+                    q.rP[i] = q.rU[i] - 1;
+                } else {
+                    const int fin = BR * q.beta[q.idx(n - 1, s)] - koff;  // first row finalised by the strip's first band
+                    q.rU[i] = fin - 1;
+                    q.rP[i] = q.rU[i];
+                }
+                q.rS[i] = q.rU[i] - 2;
+                q.rA[i] = q.rU[i] - 4;
+                if (n > 0) q.beta[i] = q.rA[i] >= 0 ? q.rA[i] / BR : 0;
+                if (n == n_solves) q.beta[i] = q.beta[q.idx(n - 1, s)];  // no solve follows the final update
+            }
+            for (int s = 1; s <= S && ok; s++) {
+                const int i = q.idx(n, s), j = q.idx(n, s - 1);
+                ok = q.beta[i] > q.beta[j] && q.rU[i] > q.rU[j] && q.rA[i] > q.rA[j] && q.rS[i] > q.rS[j] &&
+                     q.rP[i] > q.rP[j] && q.rA[i] >= 0 && q.rU[i] <= H;
+            }
+        }
+        if (ok) {
+            out = q;
+            return true;
+        }
+    }
+    return false;
+}
+
+hipEvent_t strip_event(papof_handle* h) {
+    if (h->strip_events_used == h->strip_events.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        h->strip_events.push_back(e);
+    }
+    return h->strip_events[h->strip_events_used++];
+}
+
+int smooth_flow_strips(papof_handle* h, const StripSchedule& q, const LevelInit& li, const double* f1, const double* f2,
+                       double* warp, double*& u, double*& v, double*& ua, double*& va, int H, int W, int fc, double alpha,
+                       int n_sor, double omega, SolveBuffers& B, PhaseClock& clk, PhaseClock& uclk, const double* im1s) {
+    const int S = q.S, n_outer = q.n_solves;
+    if (S < 2 || (int)h->strip_streams.size() < S - 1 || !im1s) return PAPOF_EINVAL;
+    hipStream_t const main_stream = h->stream;
+    const auto stream_of = [&](int s) { return s == S - 1 ? main_stream : h->strip_streams[s]; };
+    struct StreamSwap {
+        papof_handle* h;
+        hipStream_t saved;
+        StreamSwap(papof_handle* hh, hipStream_t s) : h(hh), saved(hh->stream) { h->stream = s; }
+        ~StreamSwap() { h->stream = saved; }
+    };
+    clk.phase(PAPOF_T_ALLOCATION);
+    PAPOF_TRY(sor_strips_begin(h, B.sp, n_sor, n_outer));  // the counters of every solve of the level, before the fork
+    hipEvent_t const fork = strip_event(h);
+    if (!fork) return PAPOF_EDEVICE;
+    PAPOF_HIP(hipEventRecord(fork, main_stream));
+    PAPOF_HIP(hipStreamWaitEvent(stream_of(0), fork, 0));  // strip s > 0 waits for strip s - 1 in every iteration
+    std::vector<hipEvent_t> done(S, nullptr);
+    const auto sor_on_main = [](void* c, int on) {
+        static_cast<PhaseClock*>(c)->phase(on ? PAPOF_T_PHASE5_SOR : PAPOF_T_PHASE6_UPDATE);
+    };
+    const auto sor_on_strip = [](void* c, int on) { static_cast<PhaseClock*>(c)->phase(on ? PAPOF_T_PHASE5_SOR : -1); };
+    for (int n = 0; n <= n_outer; n++) {
+        const bool last = n == n_outer;
+        for (int s = 0; s < S; s++) {
+            StreamSwap on_strip(h, stream_of(s));
+            const bool crit = s == S - 1;  // the lowest strip's chain (main stream) carries the stamped phase timers
+            if (s > 0) PAPOF_HIP(hipStreamWaitEvent(h->stream, done[s - 1], 0));
+            const int i0 = q.idx(n, s), i1 = q.idx(n, s + 1);
+            const Rect ru{0, q.rU[i0], W, q.rU[i1]}, rp{0, q.rP[i0], W, q.rP[i1]}, ra{0, q.rA[i0], W, q.rA[i1]};
+            const double *un = u, *vn = v;  // the flow the assembly reads
+            if (n == 0) {
+                if (!li.coarsest) {  // src/OpticalFlow.cpp:809-814
+                    if (crit) clk.phase(PAPOF_T_ALLOCATION);
+                    PAPOF_TRY(resize(h, li.pu, u, li.ph, li.pw, 1, H, W, li.xr, li.yr, true, li.inv, &ru));
+                    PAPOF_TRY(resize(h, li.pv, v, li.ph, li.pw, 1, H, W, li.xr, li.yr, true, li.inv, &ru));
+                    PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, H, W, fc, &ru));
+                }
+                if (crit) clk.phase(PAPOF_T_PHASE2_DERIVATIVES);
+                PAPOF_TRY(compute_phi(h, u, v, nullptr, B.phi, H, W, &rp));
+            } else {  // Phase6 of iteration n - 1 with the phi of iteration n folded in (the main chain's Phase6 was
+                      // opened by its solver's end mark)
+                PAPOF_TRY(update_warp_phi(h, B.sp, u, v, ua, va, f1, f2, warp, last ? nullptr : B.phi, H, W, fc, !last,
+                                          ru.y0, ru.y1));
+                un = ua;
+                vn = va;
+            }
+            if (!last) {
+                if (crit) clk.phase(PAPOF_T_PHASE1_GENERATE);
+                PAPOF_TRY(smooth_hv_blend(h, warp, im1s, B.blend, B.imdt, H, W, fc, q.rS[i0], q.rS[i1]));
+                if (crit) clk.phase(PAPOF_T_PHASE4_LINEARSYSTEM);
+                PAPOF_TRY(assemble_system(h, B.blend, B.imdt, B.phi, un, vn, H, W, fc, alpha, omega, B.sp, nullptr, nullptr,
+                                          nullptr, &ra, nullptr));
+            }
+            if (!crit) {
+                done[s] = strip_event(h);
+                if (!done[s]) return PAPOF_EDEVICE;
+                PAPOF_HIP(hipEventRecord(done[s], h->stream));
+            }
+            if (!last) {
+                h->sor_mark = crit ? +sor_on_main : +sor_on_strip;
+                h->sor_mark_ctx = crit ? &clk : &uclk;
+                const int rc = sor_solve_bands(h, B.sp, H, W, alpha, omega, n_sor, n, q.beta[i0], q.beta[i1]);
+                h->sor_mark = nullptr;
+                h->sor_mark_ctx = nullptr;
+                PAPOF_TRY(rc);
+            }
+        }
+        if (n > 0) {
+            std::swap(u, ua);
+            std::swap(v, va);
+        }
+    }
+    // join: the final update of strip S - 2 waited for strip S - 3's, and so on -- and the main stream for S - 2's
     clk.phase(-1);
     return PAPOF_OK;
 }
@@ -453,6 +643,11 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     PhaseClock pclk{h, !in_capture};
     PhaseClock total{h, !in_capture};
     clk.only_sor = pclk.only_sor = (!h->phase_events && P.phase_timing == 0) || P.phase_timing == 2;
+    PhaseClock uclk{h, !in_capture};  // solver launches of the upper strips (smooth_flow_strips): events on their streams
+    uclk.only_sor = true;
+    h->strip_events_used = 0;
+    h->sor_launches = 0;
+    h->sor_upper_sec = 0.0;
     clk.stamps = true;  // the main stream's phase boundaries are in-kernel stamps, not events (flow_internal.h)
     h->stamps_used = 0;
     h->next_stamp = nullptr;
@@ -625,6 +820,16 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
             if (overlap) PAPOF_HIP(hipStreamWaitEvent(main_stream, h->sync_events[k], 0));
             clk.phase(PAPOF_T_ALLOCATION);  // flow up-sampling and first warp of the level (:801-814)
             const double *f1 = F1[k], *f2 = F2[k];
+            const int n_sor_k = P.n_sor + k * P.n_sor_per_level, n_outer_k = P.n_outer + k * P.n_outer_per_level;
+            PAPOF_TRY(sor_bind(h, B.sp, lh, lw, n_sor_k));
+            // strips (smooth_flow_strips): big levels of the exact-order path, default branches, overlapping streams allowed
+            StripSchedule sch;
+            // OFF by default (PAPOF_STRIPS=2..4 enables): measured slower on every level it applies to
+            const int want = h->strips > 1 ? h->strips : 1;
+            const bool strips = overlap && (int)h->strip_streams.size() >= 3 && P.sor_mode == PAPOF_SOR_EXACT &&
+                                P.n_inner == 1 && !B.bgx && !B.gm && want >= 2 &&
+                                plan_strips(h, B.sp, lh, n_sor_k, n_outer_k, want, sch);
+            LevelInit li{k == levels - 1, nullptr, nullptr, ph, pw, 0.0, 0.0, 1 / ratio};
             if (k == levels - 1) {  // src/OpticalFlow.cpp:801-806
                 PAPOF_HIP(hipMemsetAsync(u, 0, np * sizeof(double), h->stream));
                 PAPOF_HIP(hipMemsetAsync(v, 0, np * sizeof(double), h->stream));
@@ -632,21 +837,32 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
                 if (B.bgx) PAPOF_TRY(bicubic_planes(h, f2, lh, lw, fc, B));
             } else {  // :809-816
                 const double xr = (double)lw / pw, yr = (double)lh / ph, inv = 1 / ratio;
-                PAPOF_TRY(resize(h, u, u2, ph, pw, 1, lh, lw, xr, yr, true, inv));
-                PAPOF_TRY(resize(h, v, v2, ph, pw, 1, lh, lw, xr, yr, true, inv));
+                if (strips) {  // up-sampling and warp happen per strip
+                    li.pu = u;
+                    li.pv = v;
+                    li.xr = xr;
+                    li.yr = yr;
+                } else {
+                    PAPOF_TRY(resize(h, u, u2, ph, pw, 1, lh, lw, xr, yr, true, inv));
+                    PAPOF_TRY(resize(h, v, v2, ph, pw, 1, lh, lw, xr, yr, true, inv));
+                }
                 std::swap(u, u2);
                 std::swap(v, v2);
-                if (!B.bgx) {
+                if (strips) {
+                } else if (!B.bgx) {
                     PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc));
                 } else {  // interpolation == Bicubic (:816): warpImageBicubicRef, no threshold here
                     PAPOF_TRY(bicubic_planes(h, f2, lh, lw, fc, B));
                     PAPOF_TRY(bicubic_warp(h, f1, f2, B.bgx, B.bgy, B.bgxy, u, v, warp, lh, lw, fc, nullptr, true, false));
                 }
             }
-            PAPOF_TRY(sor_bind(h, B.sp, lh, lw, P.n_sor + k * P.n_sor_per_level));
             PAPOF_TRY(sor_reset_planes(h, B.sp));
-            PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, u2, v2, lh, lw, fc, P.alpha, P.n_outer + k * P.n_outer_per_level,
-                                  P.n_inner, P.n_sor + k * P.n_sor_per_level, P.omega, P.sor_mode, B, clk, S1[k]));
+            if (strips)
+                PAPOF_TRY(smooth_flow_strips(h, sch, li, f1, f2, warp, u, v, u2, v2, lh, lw, fc, P.alpha, n_sor_k, P.omega, B,
+                                             clk, uclk, S1[k]));
+            else
+                PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, u2, v2, lh, lw, fc, P.alpha, n_outer_k, P.n_inner, n_sor_k,
+                                      P.omega, P.sor_mode, B, clk, S1[k], false));
             pw = lw;
             ph = lh;
         }
@@ -673,7 +889,8 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         g_last_error = "hipGraph capture failed; graph mode switched off for this handle";
         return rc_main != PAPOF_OK ? rc_main : PAPOF_EDEVICE;
     }
-    if (rc_main != PAPOF_OK) {  // never leave work of this call running on either stream
+    if (rc_main != PAPOF_OK) {  // never leave work of this call running on any stream
+        for (hipStream_t ss : h->strip_streams) hipStreamSynchronize(ss);
         hipStreamSynchronize(main_stream);
         if (overlap) hipStreamSynchronize(prep);
         return rc_main;
@@ -694,6 +911,14 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     clk.collect(tm);
     pclk.collect(tm);
     total.collect(tm);
+    if (uclk.err != PAPOF_OK) return PAPOF_EDEVICE;
+    {   // Phase5_SOR = the solver kernels' own time, all strips (on the main chain's time line only the lowest strip's)
+        double tu[PAPOF_N_TIMERS];
+        std::memset(tu, 0, sizeof tu);
+        uclk.collect(tu);
+        h->sor_upper_sec = tu[PAPOF_T_PHASE5_SOR];
+        tm[PAPOF_T_PHASE5_SOR] += tu[PAPOF_T_PHASE5_SOR];
+    }
     {   // the fused assembly kernel was recorded under Phase4: psi's share of it is Phase3_PsiData.  kPsiShare = the
         // kernel's arithmetic that belongs to :377-406 (per channel: t*t, + eps, sqrt, 2*, 1/) over all of it, counted in
         // the kernel's ISA (fp64 sqrt and division are ~25 instructions each); a fixed apportioning, not a measurement.
@@ -797,6 +1022,12 @@ int papof_create(int device, papof_handle** out) {
         papof_destroy(h);
         return PAPOF_ENODEVICE;
     }
+    for (int i = 0; i < 3; i++) {  // strip streams (smooth_flow_strips); without them levels are simply not cut
+        hipStream_t ss = nullptr;
+        if (hipStreamCreateWithFlags(&ss, hipStreamNonBlocking) != hipSuccess) break;
+        h->strip_streams.push_back(ss);
+    }
+    if (const char* cs = std::getenv("PAPOF_STRIPS")) h->strips = std::max(0, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_GRAPH")) h->use_graph = std::atoi(cs) != 0;
     if (const char* cs = std::getenv("PAPOF_OVERLAP")) h->overlap_prep = std::atoi(cs) != 0;
     if (const char* cs = std::getenv("PAPOF_PHASE_EVENTS")) h->phase_events = std::atoi(cs) != 0;
@@ -833,8 +1064,13 @@ void papof_destroy(papof_handle* h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     if (h->prep_stream) hipStreamSynchronize(h->prep_stream);
+    for (hipStream_t ss : h->strip_streams) {
+        hipStreamSynchronize(ss);
+        hipStreamDestroy(ss);
+    }
     for (hipEvent_t e : h->events) hipEventDestroy(e);
     for (hipEvent_t e : h->sync_events) hipEventDestroy(e);
+    for (hipEvent_t e : h->strip_events) hipEventDestroy(e);
     for (papof::GraphEntry& e : h->graphs)
         if (e.exec) hipGraphExecDestroy(e.exec);
     if (h->prep_stream) hipStreamDestroy(h->prep_stream);
@@ -1623,6 +1859,133 @@ int papof_sor_plan(papof_handle* h, int height, int width, int n_sor, int sor_mo
 
 // SOR micro-benchmark on synthetic planes resident in HBM: phi~U(0.5,50), imdx2/imdy2~U(0,.05),
 // imdxy~U(-.02,.02), rhs~U(-.01,.01); alpha .012, omega 1.8.
+int papof_last_sor_stats(papof_handle* h, int* launches, double* strip_streams_sec) {
+    if (!h) return PAPOF_EINVAL;
+    if (launches) *launches = h->sor_launches;
+    if (strip_streams_sec) *strip_streams_sec = h->sor_upper_sec;
+    return PAPOF_OK;
+}
+
+int papof_strip_plan(papof_handle* h, int height, int width, int n_sor, int n_outer, int want_strips, int* strips,
+                     int* out, int cap, int* band_rows, int* koff, int* bands) {
+    if (!h || !strips || height < 1 || width < 1 || n_sor < 1 || n_outer < 1) return PAPOF_EINVAL;
+    SorPlanes sp{};
+    sp.skew = true;
+    sp.cap_cells = sp.cap_cells_d = ~size_t(0);
+    PAPOF_TRY(sor_bind(h, sp, height, width, n_sor));
+    if (band_rows) *band_rows = sp.sd.band_rows;
+    if (koff) *koff = sp.sd.koff;
+    if (bands) *bands = sp.sd.nb;
+    StripSchedule q;
+    const int want = want_strips > 0 ? want_strips : (h->strips > 1 ? h->strips : 1);
+    if (!plan_strips(h, sp, height, n_sor, n_outer, want, q)) {
+        *strips = 1;
+        return PAPOF_OK;
+    }
+    *strips = q.S;
+    if (out) {
+        const int need = (n_outer + 1) * (q.S + 1) * 5;
+        if (cap < need) return PAPOF_EINVAL;
+        for (int n = 0; n <= n_outer; n++)
+            for (int s = 0; s <= q.S; s++) {
+                int* o = out + (size_t)q.idx(n, s) * 5;
+                o[0] = q.beta[q.idx(n, s)];
+                o[1] = q.rU[q.idx(n, s)];
+                o[2] = q.rP[q.idx(n, s)];
+                o[3] = q.rS[q.idx(n, s)];
+                o[4] = q.rA[q.idx(n, s)];
+            }
+    }
+    return PAPOF_OK;
+}
+
+// Test aid (papof.h): one exact-order solve on synthetic planes, whole and as two strips of bands on two streams
+// (sor_solve_bands), `reps` times; *mismatches = 16-byte cells of the (du, dv) planes, both parities, that differ.
+int papof_test_sor_strips(papof_handle* h, int height, int width, int n_sor, int split_band, int reps, int delay_us,
+                          long long* mismatches, int* bands) {
+    if (!h || !mismatches || h->strip_streams.empty()) return PAPOF_EINVAL;
+    const size_t np = (size_t)height * width;
+    Scope S(h, img_bytes(height, width, 1, 16) + sor_scratch_bytes(height, width, n_sor) +
+                   12 * (size_t)height * width * sizeof(double));
+    PAPOF_TRY(S.rc);
+    std::vector<double> host(np * 6);
+    std::mt19937_64 rng(2);
+    auto fill = [&](size_t k, double lo, double hi) {
+        std::uniform_real_distribution<double> d(lo, hi);
+        for (size_t i = 0; i < np; i++) host[k * np + i] = d(rng);
+    };
+    fill(0, 0.5, 50.0);
+    fill(1, -0.02, 0.02);
+    fill(2, 0.0, 0.05);
+    fill(3, 0.0, 0.05);
+    fill(4, -0.01, 0.01);
+    fill(5, -0.01, 0.01);
+    double* planes[6];
+    for (int k = 0; k < 6; k++) planes[k] = S.up_planar(host.data() + k * np, height, width, 1);
+    SorPlanes sp{};
+    PAPOF_TRY(alloc_sor_planes(S, height, width, PAPOF_SOR_EXACT, n_sor, sp));
+    PAPOF_TRY(sor_reset_planes(h, sp));
+    PAPOF_TRY(sor_prep(h, planes[0], planes[1], planes[2], planes[3], planes[4], planes[5], height, width, 0.012, 1.8, sp));
+    if (bands) *bands = sp.sd.nb;
+    const size_t cells = sp.sd.nd;
+    std::vector<double> want(cells * 2), got(cells * 2);
+    PAPOF_TRY(sor_solve(h, sp, height, width, 0.012, 1.8, n_sor, PAPOF_SOR_EXACT));
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    PAPOF_TRY(sor_check(h));
+    PAPOF_HIP(hipMemcpy(want.data(), sp.du, cells * 16, hipMemcpyDeviceToHost));
+    *mismatches = 0;
+    if (!sor_strips_supported(h, sp, n_sor) || split_band < 1 || split_band >= sp.sd.nb) return PAPOF_EINVAL;
+    hipStream_t const main_stream = h->stream, top = h->strip_streams[0];
+    hipEvent_t ev;
+    PAPOF_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (int r = 0; r < reps; r++) {
+        PAPOF_TRY(sor_strips_begin(h, sp, n_sor, 1));
+        PAPOF_HIP(hipEventRecord(ev, main_stream));
+        PAPOF_HIP(hipStreamWaitEvent(top, ev, 0));
+        h->stream = top;
+        int rc = sor_solve_bands(h, sp, height, width, 0.012, 1.8, n_sor, 0, 0, split_band);
+        h->stream = main_stream;
+        PAPOF_TRY(rc);
+        if (delay_us > 0) {  // the lower strip starts later, as behind its own assembly kernels
+            hipStreamSynchronize(main_stream);
+            const double t0 = wall();
+            while ((wall() - t0) * 1e6 < delay_us) {}
+        }
+        PAPOF_TRY(sor_solve_bands(h, sp, height, width, 0.012, 1.8, n_sor, 0, split_band, sp.sd.nb));
+        PAPOF_HIP(hipStreamSynchronize(top));
+        PAPOF_HIP(hipStreamSynchronize(main_stream));
+        PAPOF_TRY(sor_check(h));
+        PAPOF_HIP(hipMemcpy(got.data(), sp.du, cells * 16, hipMemcpyDeviceToHost));
+        long long mm = 0;
+        std::vector<long long> by_band(sp.sd.nb, 0), by_quad(16, 0);
+        long long by_par[2] = {0, 0};
+        int pmin = 1 << 30, pmax = -1;
+        const size_t per_par = (size_t)sp.sd.npos_d * sp.sd.nb * kLanes;
+        for (size_t i = 0; i < cells; i++)
+            if (got[2 * i] != want[2 * i] || got[2 * i + 1] != want[2 * i + 1]) {
+                ++mm;
+                const size_t par = i / per_par, rest = i % per_par;
+                const int pos = (int)(rest / ((size_t)sp.sd.nb * kLanes)), b = (int)((rest / kLanes) % sp.sd.nb), c = (int)(rest % kLanes);
+                by_par[par]++;
+                by_band[b]++;
+                by_quad[c / 4]++;
+                pmin = std::min(pmin, pos);
+                pmax = std::max(pmax, pos);
+                if (mm <= 6 && std::getenv("PAPOF_SOR_DBG")) std::fprintf(stderr, "  [split dbg] rep %d mismatch parity %zu pos %d band %d cell %d: got %.6g want %.6g\n", r, par, pos, b, c, got[2 * i], want[2 * i]);
+            }
+        if (mm && std::getenv("PAPOF_SOR_DBG")) {
+            std::fprintf(stderr, "  [split dbg] rep %d: %lld cells, parity0 %lld parity1 %lld, pos %d..%d, by band:", r, mm, by_par[0], by_par[1], pmin, pmax);
+            for (int b = 0; b < sp.sd.nb; b++) std::fprintf(stderr, " %lld", by_band[b]);
+            std::fprintf(stderr, " | by lane quad:");
+            for (int k = 0; k < 16; k++) std::fprintf(stderr, " %lld", by_quad[k]);
+            std::fprintf(stderr, "\n");
+        }
+        *mismatches += mm;
+    }
+    hipEventDestroy(ev);
+    return PAPOF_OK;
+}
+
 int papof_bench_sor(papof_handle* h, int height, int width, int n_sor, int sor_mode, int reps, unsigned seed,
                     double* ms_per_solve) {
     if (!h || !ms_per_solve || height < 1 || width < 1 || n_sor < 1 || reps < 1 || sor_mode < PAPOF_SOR_EXACT ||

@@ -11,6 +11,7 @@
 // (Code/Serial/setup.py:24-25, plain x86-64 gcc), and matching its rounding step for step is what
 // makes the GPU results bit-compatible instead of merely close.
 #pragma once
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 
@@ -255,6 +256,14 @@ struct papof_handle {
     int rb_shape = 0;                // ... region shape 1..4 (sor.hip: blocked_shape); 0 = by plane size
     int rb_naive = 0;                // 1: one launch per half-sweep on the planes (cross-check)
     int sor_resident = 0;            // tasks per launch of the exact-order kernels; 0 = 8 per CU (sor.hip: resident_tasks)
+    int sor_launches = 0;            // exact-order solver kernels launched by the current / last call (measurement: bench.py)
+    double sor_upper_sec = 0.0;      // ... of which: event time of the launches on the strip streams (added to Phase5_SOR)
+    // strips (api.hip: smooth_flow_strips): a level's plane as S horizontal strips of solver bands, each on its own
+    // stream, so that a strip's non-solver kernels run in the shadow of the other strips' solves
+    int strips = 0;                  // PAPOF_STRIPS: 0 / 1 = off (default), 2..4 = strips per level where the layout allows
+    std::vector<hipStream_t> strip_streams;  // S - 1 extra streams (the last strip runs on the main stream)
+    std::vector<hipEvent_t> strip_events;    // untimed events ordering the strips, reused from call to call
+    size_t strip_events_used = 0;
     // second stream for everything that does not depend on the flow (pyramids, features, smoothed frame 1 of every
     // level, derivative planes of the final bicubic warp): runs beside the coarse levels' latency-bound solves
     hipStream_t prep_stream = nullptr;
@@ -302,7 +311,7 @@ int warp_bilinear(papof_handle* h, const double* im1, const double* im2, const d
 int smooth_v_blend(papof_handle* h, const double* tmp, const double* im1s, double* blend, double* imdt, int H,
                    int W, int planes, const Rect* rc = nullptr);
 int smooth_hv_blend(papof_handle* h, const double* warp, const double* im1s, double* blend, double* imdt, int H,
-                    int W, int planes);
+                    int W, int planes, int row0 = 0, int row1 = -1);  // rows row0 .. row1-1 (-1: to the last row)
 int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlanes* prev, double* phi, int H, int W,
                 const Rect* rc = nullptr);
 int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,
@@ -323,7 +332,7 @@ int flow_dequantize16(papof_handle* h, const unsigned short* q, double* vx, doub
 int flow_to_bgr(papof_handle* h, const double* vx, const double* vy, size_t n, double* partial, unsigned char* bgr);
 int update_warp_phi(papof_handle* h, const SorPlanes& sp, const double* u, const double* v, double* u_out, double* v_out,
                     const double* im1, const double* im2, double* warp, double* phi_out, int H, int W, int planes,
-                    bool do_warp = true);
+                    bool do_warp = true, int row0 = 0, int row1 = -1);
 int update_flow(papof_handle* h, const SorPlanes& sp, double* u, double* v, int H, int W, const Rect& r);
 int sor_prep(papof_handle* h, const double* phi, const double* imdxy, const double* imdx2, const double* imdy2,
              const double* rhs1, const double* rhs2, int H, int W, double alpha, double omega, const SorPlanes& out);
@@ -342,6 +351,12 @@ int sor_blocked_launch(papof_handle* h, const SorPlanes& sp, int H, int W, doubl
                        int hs0, const Rect& out, const double* su, const double* sv, double* du, double* dv);
 int sor_plan(const papof_handle* h, int H, int W, int n_sor, int mode, int* launches, int* depth);
 int sor_check(papof_handle* h);  // after a stream sync: PAPOF_ETIMEOUT if a device-side wait expired
+// one solve as strips of bands on several streams (sor.hip): can this bound layout be solved in strips; clear the
+// counters of all `n_solves` solves of a level (before the streams fork); launch bands b0 .. b1-1 of solve `solve_idx`
+bool sor_strips_supported(const papof_handle* h, const SorPlanes& sp, int n_sor);
+int sor_strips_begin(papof_handle* h, const SorPlanes& sp, int n_sor, int n_solves);
+int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor,
+                    int solve_idx, int b0, int b1);
 int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes& sp);  // carve the operand planes
 int sor_bind(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor);  // choose the layout of the next solves (skew mode)
 int sor_group_size(const papof_handle* h, int H, int W, int n_sor);   // sweeps per workgroup the solver will use

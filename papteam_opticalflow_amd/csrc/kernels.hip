@@ -224,10 +224,11 @@ constexpr int kFuseRows = 16;
 __global__ __launch_bounds__(256) void k_smooth_hv_blend(const double* __restrict__ warp,
                                                          const double* __restrict__ im1s,
                                                          double* __restrict__ blend, double* __restrict__ imdt, int H,
-                                                         int W, Taps g, unsigned long long* stamp) {
+                                                         int W, Taps g, unsigned long long* stamp, int row0, int row1) {
     __shared__ double hs[kFuseRows + 4][BX];
     stamp_now(stamp);
-    const int j = blockIdx.x * BX + threadIdx.x, i0 = blockIdx.y * kFuseRows;
+    // rows row0 .. row1-1 are written (a strip of the plane, api.hip: smooth_flow_strips; the whole plane otherwise)
+    const int j = blockIdx.x * BX + threadIdx.x, i0 = row0 + blockIdx.y * kFuseRows;
     const size_t np = (size_t)H * W;
     const double* src = warp + blockIdx.z * np;
     if (j < W) {
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void k_smooth_hv_blend(const double* __restric
     if (j >= W) return;
     for (int r = threadIdx.y; r < kFuseRows; r += BY) {
         const int i = i0 + r;
-        if (i >= H) break;
+        if (i >= row1) break;
         const size_t o = blockIdx.z * np + (size_t)i * W + j;
         double s2 = 0.0;
 #pragma unroll
@@ -547,16 +548,17 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
                                                        double2s* __restrict__ pa, double2s* __restrict__ pb,
                                                        double2s* __restrict__ pc, double* __restrict__ o_x2,
                                                        double* __restrict__ o_y2, Taps d, Increment I,
-                                                       unsigned long long* stamp) {
+                                                       unsigned long long* stamp, int row0, int row1) {
     __shared__ double stage[6][kBandRows][kTileJ + 1];
     stamp_now(stamp);
-    const int b = blockIdx.y, j0 = blockIdx.x * kTileJ, tid = threadIdx.x;
+    // tiles start at row0 and rows row0 .. row1-1 are written (a strip of the plane; the whole plane otherwise)
+    const int ib = row0 + blockIdx.y * kBandRows, j0 = blockIdx.x * kTileJ, tid = threadIdx.x;
     // block-uniform: no cell of this tile is closer than 2 pixels to an image border
-    const bool interior = b * kBandRows >= 2 && b * kBandRows + kBandRows + 2 <= H && j0 >= 2 && j0 + kTileJ + 2 <= W;
+    const bool interior = ib >= 2 && ib + kBandRows + 2 <= H && j0 >= 2 && j0 + kTileJ + 2 <= W;
     for (int c = tid; c < kBandRows * kTileJ; c += 256) {
         const int r = c / kTileJ, jj = c - r * kTileJ;
-        const int i = b * kBandRows + r, j = j0 + jj;
-        if (i < H && j < W) {
+        const int i = ib + r, j = j0 + jj;
+        if (i < row1 && j < W) {
             const SystemCell s =
                 interior ? assemble_cell<false>(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I)
                          : assemble_cell<true>(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I);
@@ -577,8 +579,8 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
     for (int pp = g; pp <= kBandRows + kTileJ - 2; pp += 256 / kTileJ) {  // pp = jj + (row in tile)
         const int r = pp - jj;
         if (r < 0 || r >= kBandRows) continue;
-        const int i = b * kBandRows + r;
-        if (i >= H) continue;
+        const int i = ib + r;
+        if (i >= row1) continue;
         const size_t q = skew_cell(i, j, sk);
         pa[q] = double2s{stage[0][r][jj], stage[1][r][jj]};
         pb[q] = double2s{stage[2][r][jj], stage[3][r][jj]};
@@ -655,10 +657,10 @@ __global__ void k_update_warp_phi(const double* __restrict__ sdu, const double* 
                                   double* __restrict__ u_out, double* __restrict__ v_out,
                                   const double* __restrict__ im1, const double* __restrict__ im2,
                                   double* __restrict__ warp, double* __restrict__ phi_out, int H, int W, int planes,
-                                  int do_warp, unsigned long long* stamp) {
+                                  int do_warp, unsigned long long* stamp, int row0, int row1) {
     stamp_now(stamp);
-    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
-    if (j >= W || i >= H) return;
+    const int j = blockIdx.x * BX + threadIdx.x, i = row0 + blockIdx.y * BY + threadIdx.y;  // rows row0 .. row1-1
+    if (j >= W || i >= row1) return;
     const size_t o = (size_t)i * W + j;
     const auto inc = [&](int ii, int jj, double& a, double& b) {
         if (SKEW) {
@@ -1025,9 +1027,13 @@ static Increment increment_of(const SorPlanes* prev, const double* gm = nullptr)
 }
 
 int smooth_hv_blend(papof_handle* h, const double* warp, const double* im1s, double* blend, double* imdt, int H,
-                    int W, int planes) {
-    hipLaunchKernelGGL(k_smooth_hv_blend, dim3((W + BX - 1) / BX, (H + kFuseRows - 1) / kFuseRows, planes),
-                       dim3(BX, BY), 0, h->stream, warp, im1s, blend, imdt, H, W, smooth5_taps(), take_stamp(h));
+                    int W, int planes, int row0, int row1) {
+    if (row1 < 0) row1 = H;
+    if (row0 < 0 || row1 > H) return PAPOF_EINVAL;
+    if (row1 <= row0) return PAPOF_OK;
+    hipLaunchKernelGGL(k_smooth_hv_blend, dim3((W + BX - 1) / BX, (row1 - row0 + kFuseRows - 1) / kFuseRows, planes),
+                       dim3(BX, BY), 0, h->stream, warp, im1s, blend, imdt, H, W, smooth5_taps(), take_stamp(h), row0,
+                       row1);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
@@ -1049,11 +1055,11 @@ int assemble_system(papof_handle* h, const double* blend, const double* imdt, co
     const Rect r = region(rc, W, H);
     if (r.empty()) return PAPOF_OK;
     if (out.skew) {
-        if (rc) return PAPOF_EINVAL;  // regions exist for the row-major (tile) path only
-        hipLaunchKernelGGL(k_assemble_skew, dim3((W + kTileJ - 1) / kTileJ, (H + kBandRows - 1) / kBandRows),
+        if (rc && (r.x0 != 0 || r.x1 != W)) return PAPOF_EINVAL;  // skew layout: whole rows only (strips of a plane)
+        hipLaunchKernelGGL(k_assemble_skew, dim3((W + kTileJ - 1) / kTileJ, (r.y1 - r.y0 + kBandRows - 1) / kBandRows),
                            dim3(256), 0, h->stream, blend, imdt, phi, u, v, H, W, planes, alpha, omega, skew_idx(out),
                            (double2s*)out.phi, (double2s*)out.a1, (double2s*)out.b1, opt_imdx2, opt_imdy2,
-                           deriv5_taps(), I, take_stamp(h));
+                           deriv5_taps(), I, take_stamp(h), r.y0, r.y1);
     } else {
         hipLaunchKernelGGL(k_assemble, grid2d(r), dim3(BX, BY), 0, h->stream, blend, imdt, phi, u, v, H, W, planes,
                            alpha, omega, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2, opt_imdx2, opt_imdy2,
@@ -1084,15 +1090,20 @@ int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, 
 
 int update_warp_phi(papof_handle* h, const SorPlanes& sp, const double* u, const double* v, double* u_out, double* v_out,
                     const double* im1, const double* im2, double* warp, double* phi_out, int H, int W, int planes,
-                    bool do_warp) {
+                    bool do_warp, int row0, int row1) {
     if (u == u_out || v == v_out) return PAPOF_EINVAL;
+    if (row1 < 0) row1 = H;
+    if (row0 < 0 || row1 > H) return PAPOF_EINVAL;
+    if (row1 <= row0) return PAPOF_OK;
+    const dim3 grid = grid2d(W, row1 - row0);
     if (sp.skew)
-        hipLaunchKernelGGL(k_update_warp_phi<true>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv, skew_idx(sp),
-                           u, v, u_out, v_out, im1, im2, warp, phi_out, H, W, planes, do_warp ? 1 : 0, take_stamp(h));
+        hipLaunchKernelGGL(k_update_warp_phi<true>, grid, dim3(BX, BY), 0, h->stream, sp.du, sp.dv, skew_idx(sp),
+                           u, v, u_out, v_out, im1, im2, warp, phi_out, H, W, planes, do_warp ? 1 : 0, take_stamp(h),
+                           row0, row1);
     else
-        hipLaunchKernelGGL(k_update_warp_phi<false>, grid2d(W, H), dim3(BX, BY), 0, h->stream, sp.du, sp.dv,
+        hipLaunchKernelGGL(k_update_warp_phi<false>, grid, dim3(BX, BY), 0, h->stream, sp.du, sp.dv,
                            SkewIdx{0, 0, 0, 0, 0, 0, 0, 0, 0}, u, v, u_out, v_out, im1, im2, warp, phi_out, H, W, planes,
-                           do_warp ? 1 : 0, take_stamp(h));
+                           do_warp ? 1 : 0, take_stamp(h), row0, row1);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }

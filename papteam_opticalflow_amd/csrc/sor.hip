@@ -99,6 +99,8 @@ struct ExactArgs {
     int xcd_affine;
     int k0;  // first sweep (k_sor_exact) / pair (k_sor_fused) of THIS launch: a solve whose tasks exceed what the chip
              // keeps resident is issued as consecutive launches over ranges of sweeps (sor_solve)
+    int b0, nbl;  // bands b0 .. b0 + nbl - 1 are THIS launch's (a strip of the plane, sor_solve_bands: the strips of a solve
+                  // are launched on different streams and meet through the progress counters); a whole solve: 0, nb
     double nalpha, om1;
     unsigned long long* dbg;  // diagnostics (PAPOF_SOR_DBG): per task 8 time stamps (s_memrealtime, 100 MHz), else null
     unsigned long long* stamp;  // phase stamp (flow_internal.h: PhaseClock): block 0 writes the 100 MHz clock on entry
@@ -442,9 +444,9 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
             b = 8 * nf + j;
         }
     } else {
-        const int kl = blockIdx.x / A.nb;
+        const int kl = blockIdx.x / A.nbl;
         k = A.k0 + kl;
-        b = blockIdx.x - kl * A.nb;
+        b = A.b0 + (blockIdx.x - kl * A.nbl);
     }
     const int ns = A.ns;
     const bool ghost = lane == 0 || lane == kLanes - 1;
@@ -614,11 +616,16 @@ __device__ __forceinline__ void f_step(const ExactArgs& A, const Task& T, const 
     if (SKIP2) {  // steps 0 and 1: every lane is still left of column 0
         duN2 = 0.0;
         dvN2 = 0.0;
-    } else if (ID2) {
-        duN2 = S2.duC;
-        dvN2 = S2.dvC;
     } else {
-        const D2 qa = as_d2(c.pa[t2]), qb = as_d2(c.pb[t2]), qc = as_d2(c.pc[t2]);
+        // ID2 -- the identity second sweep of the LAST pair of an odd sweep count -- is the same arithmetic with (a1, a2)
+        // masked to zero and 1 - omega -> 1 (F.om1b, set by the kernel): the exact pass-through the ghost lanes use.  (A
+        // shortcut that simply forwarded the first sweep's results two steps later, without the arithmetic, returned wrong
+        // cells -- a quad of lanes here and there -- whenever OTHER kernels ran on the chip at the same time: three handles
+        // in flight, or a solve cut into strips; never alone.  Same source semantics, so a code-generation hazard of that
+        // variant; not pursued further, the variant is gone.  tests/test_gpu_parity.py keeps the reproducer.)
+        const D2 qa = as_d2(c.pa[t2]), qc = as_d2(c.pc[t2]);
+        const u32x4 qbm = ID2 ? (c.pb[t2] & u32x4{0u, 0u, 0u, 0u}) : c.pb[t2];
+        const D2 qb = as_d2(qbm);
         const double phiC = qa.x, xy = qa.y;
         const double duU = from_above<DPP>(S2.duL);
         const double dvU = from_above<DPP>(S2.dvL);
@@ -771,9 +778,9 @@ __global__ __launch_bounds__(64) void k_sor_fused(ExactArgs A) {
             b = 8 * nf + j;
         }
     } else {
-        const int ql = blockIdx.x / A.nb;
+        const int ql = blockIdx.x / A.nbl;
         q = A.k0 + ql;
-        b = blockIdx.x - ql * A.nb;
+        b = A.b0 + (blockIdx.x - ql * A.nbl);
     }
     Task T;
     const unsigned plane_bytes = (unsigned)(((size_t)A.npos * A.hp + kLanes) * 16u);
@@ -804,6 +811,7 @@ __global__ __launch_bounds__(64) void k_sor_fused(ExactArgs A) {
     F.m1 = real1 ? 0xffffffffu : 0u;
     F.om1a = real1 ? A.om1 : 1.0;
     F.om1b = (lane == 0 || lane == kLanes - 1) ? 1.0 : A.om1;
+    if ((A.n_sor & 1) && q == pairs - 1) F.om1b = 1.0;  // identity second sweep (f_step: ID2)
     F.first_out = lane == kLanes - 2;
     F.own_block = lane >= 2;
 
@@ -1830,6 +1838,8 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.nalpha = nalpha;
         A.om1 = om1;
         A.k0 = 0;
+        A.b0 = 0;
+        A.nbl = sd.nb;
         A.dbg = h->sor_dbg;
         // Fault injection for the tests (tests/test_gpu_parity.py): raise the abort word before the launch, as a task whose
         // bounded wait expired would -- every task must then END (s_endpgm on the fast path, the polling loops' abort
@@ -1880,6 +1890,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             const int chunk = std::max(1, resident_tasks(h) / (per_g * sd.group));
             for (int g0 = 0; g0 < groups; g0 += chunk) {
                 Ga.g0 = g0;
+                h->sor_launches++;
                 Ga.stamp = nullptr;  // no stamp at the head of the critical task (flow_internal.h: PhaseClock)
                 const dim3 ggrid(per_g * std::min(chunk, groups - g0));
                 if (sd.group == 4 && Rg >= 12)
@@ -1907,6 +1918,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             const int chunk = std::max(1, resident_tasks(h) / per_q);
             for (int q0 = 0; q0 < pairs; q0 += chunk) {
                 A.k0 = q0;
+                h->sor_launches++;
                 A.stamp = nullptr;
                 const dim3 fgrid(per_q * std::min(chunk, pairs - q0));
                 if (Rf <= 6)
@@ -1935,6 +1947,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         const int chunk = std::max(1, resident_tasks(h) / per_k);
         for (int k0 = 0; k0 < n_sor; k0 += chunk) {
             A.k0 = k0;
+            h->sor_launches++;
             A.stamp = nullptr;
             const dim3 grid(per_k * std::min(chunk, n_sor - k0));
             if (!h->use_dpp)
@@ -1996,6 +2009,127 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         return PAPOF_OK;
     }
     return PAPOF_EINVAL;
+}
+
+// ---- one solve as STRIPS of bands on several streams (api.hip: smooth_flow_strips) -------------------------
+// The bands b0 .. b1-1 of a solve are one launch; the launches of a solve run on different streams and meet through the
+// progress counters exactly as the tasks of one launch do (a task waits on (b, k-1), (b-1, k) and -- write-after-read --
+// (b+1, k-2): the first two point into the same or the upper strip, the third into the same or the LOWER one, so an upper
+// strip can run at most two sweeps per band ahead of the strip below it; every wait is bounded).  Because a strip starts
+// before the strips below it have even been launched, the counters of a solve must be zero before its FIRST strip
+// starts: every solve of a level has its own counter array, all cleared at once by sor_strips_begin() before the
+// streams fork.  The (du, dv) blocks of the strip's bands are cleared by the strip itself (cache warming, sor_solve).
+__global__ void k_sor_clear_bands(uint4* __restrict__ d, int nb, int b0, int nbl, unsigned n16) {
+    // the 16-byte cells [position][band b0 .. b0+nbl-1][64] of both parities; n16 = positions * nbl * 64
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n16) return;
+    const unsigned per = (unsigned)nbl * kLanes, pos = t / per, r = t - pos * per;
+    d[((size_t)pos * nb + b0) * kLanes + r] = uint4{0u, 0u, 0u, 0u};
+}
+
+bool sor_strips_supported(const papof_handle* h, const SorPlanes& sp, int n_sor) {
+    if (!sp.skew || sp.sd.group > 1 || !h->use_dpp || n_sor < 3) return false;
+    if (h->sor_xcd_affine && (sp.sd.nb <= 8 || h->sor_xcd_affine > 1)) return false;  // the XCD-affine task mapping
+    const int per = sp.sd.nb, tasks = per * (sp.sd.fuse == 2 ? (n_sor + 1) / 2 : n_sor);
+    return tasks <= resident_tasks(h);  // one launch per strip: every task of the solve resident
+}
+
+int sor_strips_begin(papof_handle* h, const SorPlanes& sp, int n_sor, int n_solves) {
+    const SkewDims& sd = sp.sd;
+    const size_t per = (size_t)sd.nb * n_sor * kProgStride, words = per * n_solves + kProgStride;
+    if (words > h->sync_cap) {
+        PAPOF_HIP(hipStreamSynchronize(h->stream));
+        if (h->sync_words) PAPOF_HIP(hipFree(h->sync_words));
+        h->sync_words = nullptr;
+        h->sync_cap = 0;
+        const size_t cap = (words + 1023) & ~size_t(1023);
+        PAPOF_HIP(hipMalloc((void**)&h->sync_words, cap * sizeof(unsigned)));
+        h->sync_cap = cap;
+        PAPOF_HIP(hipMemsetAsync(h->sync_words, 0, cap * sizeof(unsigned), h->stream));
+    } else {
+        PAPOF_HIP(hipMemsetAsync(h->sync_words + kProgStride, 0, per * n_solves * sizeof(unsigned), h->stream));
+    }
+    if (std::getenv("PAPOF_SOR_INJECT_ABORT"))  // fault injection for the tests, as in sor_solve
+        PAPOF_HIP(hipMemsetAsync(h->sync_words, 1, sizeof(unsigned), h->stream));
+    return PAPOF_OK;
+}
+
+int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor,
+                    int solve_idx, int b0, int b1) {
+    if (!sp.skew || n_sor <= 0) return PAPOF_EINVAL;
+    const SkewDims sd = skew_dims(H, W, n_sor, sp.sd.group, sp.sd.fuse);
+    if (sd.fuse != sp.sd.fuse || sd.hp != sp.sd.hp || sd.npos != sp.sd.npos || sd.qt != sp.sd.qt || sd.nb != sp.sd.nb ||
+        sd.n_sor != sp.sd.n_sor || sd.n > sp.cap_cells || sd.nd + sd.nh > sp.cap_cells_d || sd.group > 1)
+        return PAPOF_EINVAL;
+    if ((sd.n + kLanes) * 16 >= (size_t(1) << 30) || (sd.nd + sd.nh) * 16 >= (size_t(1) << 30)) return PAPOF_EINVAL;
+    if (b0 < 0 || b1 > sd.nb || b1 <= b0 || solve_idx < 0) return PAPOF_EINVAL;
+    const size_t per = (size_t)sd.nb * n_sor * kProgStride;
+    if (per * (solve_idx + 1) + kProgStride > h->sync_cap) return PAPOF_EINVAL;  // sor_strips_begin() sized the counters
+    const int nbl = b1 - b0;
+    {
+        const unsigned n16 = (unsigned)(2 * sd.npos_d) * (unsigned)nbl * kLanes;
+        hipLaunchKernelGGL(k_sor_clear_bands, dim3((n16 + 255) / 256), dim3(256), 0, h->stream, (uint4*)sp.du, sd.nb, b0,
+                           nbl, n16);
+    }
+    ExactArgs A;
+    A.phi = sp.phi;
+    A.xy = sp.xy;
+    A.a1 = sp.a1;
+    A.a2 = sp.a2;
+    A.b1 = sp.b1;
+    A.b2 = sp.b2;
+    A.du = sp.du;
+    A.dv = sp.dv;
+    A.prog = h->sync_words + kProgStride + per * solve_idx;
+    A.abort = h->sync_words;
+    A.H = H;
+    A.W = W;
+    A.nb = sd.nb;
+    A.ns = sd.ns;
+    A.hp = sd.hp;
+    A.npos = sd.npos;
+    A.qt = sd.qt;
+    A.rt = sd.rt;
+    A.npos_d = sd.npos_d;
+    A.n_sor = n_sor;
+    A.nalpha = -alpha;
+    A.om1 = 1 - omega;
+    A.k0 = 0;
+    A.b0 = b0;
+    A.nbl = nbl;
+    A.xcd_affine = 0;
+    A.dbg = nullptr;
+    A.stamp = nullptr;
+    if (h->sor_mark) h->sor_mark(h->sor_mark_ctx, 1);
+    if (sd.fuse == 2) {
+        const int pairs = (n_sor + 1) / 2, Rf = h->sor_depth > 0 ? h->sor_depth : 6;
+        const dim3 grid(nbl * pairs);
+        if (Rf <= 6)
+            hipLaunchKernelGGL((k_sor_fused<6, true>), grid, dim3(kLanes), 0, h->stream, A);
+        else if (Rf <= 8)
+            hipLaunchKernelGGL((k_sor_fused<8, true>), grid, dim3(kLanes), 0, h->stream, A);
+        else if (Rf <= 10)
+            hipLaunchKernelGGL((k_sor_fused<10, true>), grid, dim3(kLanes), 0, h->stream, A);
+        else
+            hipLaunchKernelGGL((k_sor_fused<12, true>), grid, dim3(kLanes), 0, h->stream, A);
+    } else {
+        const int R = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 8 ? 8 : 6);
+        const dim3 grid(nbl * n_sor);
+        if (R <= 4)
+            hipLaunchKernelGGL((k_sor_exact<4, true>), grid, dim3(kLanes), 0, h->stream, A);
+        else if (R <= 6)
+            hipLaunchKernelGGL((k_sor_exact<6, true>), grid, dim3(kLanes), 0, h->stream, A);
+        else if (R <= 8)
+            hipLaunchKernelGGL((k_sor_exact<8, true>), grid, dim3(kLanes), 0, h->stream, A);
+        else if (R <= 10)
+            hipLaunchKernelGGL((k_sor_exact<10, true>), grid, dim3(kLanes), 0, h->stream, A);
+        else
+            hipLaunchKernelGGL((k_sor_exact<12, true>), grid, dim3(kLanes), 0, h->stream, A);
+    }
+    PAPOF_HIP(hipGetLastError());
+    h->sor_launches++;
+    if (h->sor_mark) h->sor_mark(h->sor_mark_ctx, 0);
+    return PAPOF_OK;
 }
 
 // All skew positions that are not real cells must read as 0.0 (the kernel relies on it instead of predicates).

@@ -392,6 +392,34 @@ def test_sor_exact_more_tasks_than_the_chip_keeps_resident(gpu, oracle):
     assert np.array_equal(du, eu) and np.array_equal(dv, ev)
 
 
+@pytest.mark.parametrize("n_sor", [9, 33])
+def test_odd_sweep_counts_with_other_kernels_on_the_chip(n_sor):
+    """Regression (round 2): the two-sweeps-per-wave kernel's last pair of an ODD sweep count (identity second sweep) used
+    to return wrong cells when other kernels ran on the chip at the same time -- never alone, so every single-stream
+    test passed.  Three handles in flight, each must reproduce the bits of the solo call."""
+    import threading
+    from papteam_opticalflow_amd import Papof
+    a, b = cases.load_pair("1920")
+    hs = [Papof(0) for _ in range(3)]
+    try:
+        run = lambda g: g.coarse2fine_flow_sched(a, b, 1, 0.012, 0.75, 2, 0, 1, n_sor, 0)[0]
+        want = run(hs[0])
+        bad = [0, 0, 0]
+
+        def work(i):
+            for _ in range(8):
+                bad[i] += not np.array_equal(run(hs[i]), want)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert bad == [0, 0, 0], "wrong results per handle: %s of 8" % bad
+    finally:
+        for g in hs:
+            g.close()
+
+
 def test_sor_plan_reports_how_a_solve_is_issued(gpu):
     """papof_sor_plan (bench.py prices the roofline's per-launch figures with it): the exact-order kernels run a solve as
     ONE launch unless it has more tasks than the chip keeps resident; the blocked red-black kernel runs 10 half-sweeps
