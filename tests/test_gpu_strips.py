@@ -59,7 +59,7 @@ def test_strips_sequence_and_graph_replay(monkeypatch):
     """strips inside a captured hipGraph (forked streams joined again) and in sequence mode"""
     from papteam_opticalflow_amd import Papof
     monkeypatch.setenv("PAPOF_STRIPS", "2")
-    frames = [cases.load_frame_u8("960", i + 1) for i in range(3)]
+    frames = [cases.load_frame_u8("960", i) for i in (1, 2, 1)]  # the 960 fixture holds two frames
     g = Papof(0)
     monkeypatch.delenv("PAPOF_STRIPS")
     ref = Papof(0)
