@@ -392,23 +392,26 @@ def test_sor_exact_more_tasks_than_the_chip_keeps_resident(gpu, oracle):
     assert np.array_equal(du, eu) and np.array_equal(dv, ev)
 
 
-@pytest.mark.parametrize("n_sor", [9, 33])
-def test_odd_sweep_counts_with_other_kernels_on_the_chip(n_sor):
+@pytest.mark.parametrize("res,levels,n_outer,n_sor", [("1920", 1, 2, 9), ("1920", 1, 2, 33), ("1920", 5, 3, 30),
+                                                      ("960", 3, 2, 7), ("480", 5, 2, 5)])
+def test_results_do_not_depend_on_other_kernels_on_the_chip(res, levels, n_outer, n_sor):
     """Regression (round 2): the two-sweeps-per-wave kernel's last pair of an ODD sweep count (identity second sweep) used
     to return wrong cells when other kernels ran on the chip at the same time -- never alone, so every single-stream
-    test passed.  Three handles in flight, each must reproduce the bits of the solo call."""
+    test passed.  Three handles in flight, each must reproduce the bits of the solo call: the odd
+    counts that failed (1080p: 13 of 36 calls wrong at 33 sweeps), and the other solver kernels for good measure (config 4
+    on five levels; odd counts on the plain kernel and on levels with XCD-affine task mapping)."""
     import threading
     from papteam_opticalflow_amd import Papof
-    a, b = cases.load_pair("1920")
+    a, b = cases.load_pair(res)
     hs = [Papof(0) for _ in range(3)]
     try:
-        run = lambda g: g.coarse2fine_flow_sched(a, b, 1, 0.012, 0.75, 2, 0, 1, n_sor, 0)[0]
+        run = lambda g: g.coarse2fine_flow_sched(a, b, levels, 0.012, 0.75, n_outer, 0, 1, n_sor, 0)[:3]
         want = run(hs[0])
         bad = [0, 0, 0]
 
         def work(i):
             for _ in range(8):
-                bad[i] += not np.array_equal(run(hs[i]), want)
+                bad[i] += not all(np.array_equal(x, y) for x, y in zip(run(hs[i]), want))
         th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
         for t in th:
             t.start()
