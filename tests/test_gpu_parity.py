@@ -392,20 +392,23 @@ def test_sor_exact_more_tasks_than_the_chip_keeps_resident(gpu, oracle):
     assert np.array_equal(du, eu) and np.array_equal(dv, ev)
 
 
-@pytest.mark.parametrize("res,levels,n_outer,n_sor", [("1920", 1, 2, 9), ("1920", 1, 2, 33), ("1920", 5, 3, 30),
-                                                      ("960", 3, 2, 7), ("480", 5, 2, 5)])
-def test_results_do_not_depend_on_other_kernels_on_the_chip(res, levels, n_outer, n_sor):
+@pytest.mark.parametrize("res,levels,n_outer,n_sor,mode", [("1920", 1, 2, 9, 0), ("1920", 1, 2, 33, 0), ("1920", 5, 3, 30, 0),
+                                                           ("960", 3, 2, 7, 0), ("480", 5, 2, 5, 0), ("1920", 3, 2, 30, 1),
+                                                           ("960", 3, 2, 9, 2)])
+def test_results_do_not_depend_on_other_kernels_on_the_chip(res, levels, n_outer, n_sor, mode):
     """Regression (round 2): the two-sweeps-per-wave kernel's last pair of an ODD sweep count (identity second sweep) used
     to return wrong cells when other kernels ran on the chip at the same time -- never alone, so every single-stream
     test passed.  Three handles in flight, each must reproduce the bits of the solo call: the odd
     counts that failed (1080p: 13 of 36 calls wrong at 33 sweeps), and the other solver kernels for good measure (config 4
-    on five levels; odd counts on the plain kernel and on levels with XCD-affine task mapping)."""
+    on five levels; odd counts on the plain kernel and on levels with XCD-affine task mapping; the blocked red-black and
+    Jacobi kernels)."""
     import threading
     from papteam_opticalflow_amd import Papof
     a, b = cases.load_pair(res)
     hs = [Papof(0) for _ in range(3)]
     try:
-        run = lambda g: g.coarse2fine_flow_sched(a, b, levels, 0.012, 0.75, n_outer, 0, 1, n_sor, 0)[:3]
+        run = lambda g: g.coarse2fine_flow_sched(a, b, levels, 0.012, 0.75, n_outer, 0, 1, n_sor, 0, mode=mode,
+                                                 omega=1.0 if mode == 2 else 1.8)[:3]
         want = run(hs[0])
         bad = [0, 0, 0]
 
