@@ -263,8 +263,12 @@ int bicubic_planes(papof_handle* h, const double* f2, int H, int W, int fc, Solv
 int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* warp, double*& u, double*& v, double*& ua,
                 double*& va, int H, int W, int fc, double alpha, int n_outer, int n_inner, int n_sor, double omega,
                 int mode, SolveBuffers& B, PhaseClock& clk, const double* im1s_ready = nullptr,
-                bool final_warp = true) {
+                bool final_warp = true, unsigned* prog = nullptr, size_t prog_per_solve = 0, double* out_u = nullptr,
+                double* out_v = nullptr) {
+    // prog: cleared progress counters of this level's solves (solve i: prog + i * prog_per_solve), or null;
+    // out_u / out_v: where the LAST update writes the flow instead of the other pair of planes (the caller's result buffers)
     const Taps g = smooth5_taps();
+    int solve_idx = 0;
     const double* im1s = im1s_ready;  // smoothed frame 1: constant within the level (prepared ahead by flow_device)
     if (!im1s) {
         clk.phase(PAPOF_T_PHASE1_GENERATE);
@@ -297,7 +301,10 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
                 static_cast<PhaseClock*>(c)->phase(on ? PAPOF_T_PHASE5_SOR : PAPOF_T_PHASE6_UPDATE);
             };
             h->sor_mark_ctx = &clk;
+            h->sor_prog_next = prog ? prog + (size_t)solve_idx * prog_per_solve : nullptr;
+            solve_idx++;
             const int rc_solve = sor_solve(h, B.sp, H, W, alpha, omega, n_sor, mode);
+            h->sor_prog_next = nullptr;
             h->sor_mark = nullptr;
             h->sor_mark_ctx = nullptr;
             PAPOF_TRY(rc_solve);
@@ -307,9 +314,15 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
         // the re-warp after the LAST outer iteration of a level (:516) is read by nobody when the caller is flow_device (the
         // next level warps anew, the result is the bicubic warp of the originals): final_warp = false skips it
         const bool rewarp = !B.bgx && (final_warp || count + 1 < n_outer || B.gm);
-        PAPOF_TRY(update_warp_phi(h, B.sp, u, v, ua, va, f1, f2, warp, phi_next, H, W, fc, rewarp));
-        std::swap(u, ua);
-        std::swap(v, va);
+        if (out_u && out_v && count + 1 == n_outer) {  // the level's result goes straight to the caller's buffers
+            PAPOF_TRY(update_warp_phi(h, B.sp, u, v, out_u, out_v, f1, f2, warp, phi_next, H, W, fc, rewarp));
+            u = out_u;
+            v = out_v;
+        } else {
+            PAPOF_TRY(update_warp_phi(h, B.sp, u, v, ua, va, f1, f2, warp, phi_next, H, W, fc, rewarp));
+            std::swap(u, ua);
+            std::swap(v, va);
+        }
         if (B.bgx)  // interpolation == Bicubic: warpImageBicubicRef + threshold() on the feature planes
             PAPOF_TRY(bicubic_warp(h, f1, f2, B.bgx, B.bgy, B.bgxy, u, v, warp, H, W, fc, nullptr, true, true));
         if (B.gm) PAPOF_TRY(est_gaussian_mixture(h, f1, warp, H, W, fc, B.gm, B.gm_scratch));  // :524-528
@@ -426,9 +439,10 @@ hipEvent_t strip_event(papof_handle* h) {
 
 int smooth_flow_strips(papof_handle* h, const StripSchedule& q, const LevelInit& li, const double* f1, const double* f2,
                        double* warp, double*& u, double*& v, double*& ua, double*& va, int H, int W, int fc, double alpha,
-                       int n_sor, double omega, SolveBuffers& B, PhaseClock& clk, PhaseClock& uclk, const double* im1s) {
+                       int n_sor, double omega, SolveBuffers& B, PhaseClock& clk, PhaseClock& uclk, const double* im1s,
+                       unsigned* prog, size_t prog_per_solve, double* out_u, double* out_v) {
     const int S = q.S, n_outer = q.n_solves;
-    if (S < 2 || (int)h->strip_streams.size() < S - 1 || !im1s) return PAPOF_EINVAL;
+    if (S < 2 || (int)h->strip_streams.size() < S - 1 || !im1s || !prog) return PAPOF_EINVAL;
     hipStream_t const main_stream = h->stream;
     const auto stream_of = [&](int s) { return s == S - 1 ? main_stream : h->strip_streams[s]; };
     struct StreamSwap {
@@ -438,8 +452,7 @@ int smooth_flow_strips(papof_handle* h, const StripSchedule& q, const LevelInit&
         ~StreamSwap() { h->stream = saved; }
     };
     clk.phase(PAPOF_T_ALLOCATION);
-    PAPOF_TRY(sor_strips_begin(h, B.sp, n_sor, n_outer));  // the counters of every solve of the level, before the fork
-    hipEvent_t const fork = strip_event(h);
+    hipEvent_t const fork = strip_event(h);  // (the counters of every solve were cleared before the streams fork: `prog`)
     if (!fork) return PAPOF_EDEVICE;
     PAPOF_HIP(hipEventRecord(fork, main_stream));
     PAPOF_HIP(hipStreamWaitEvent(stream_of(0), fork, 0));  // strip s > 0 waits for strip s - 1 in every iteration
@@ -468,10 +481,12 @@ int smooth_flow_strips(papof_handle* h, const StripSchedule& q, const LevelInit&
                 PAPOF_TRY(compute_phi(h, u, v, nullptr, B.phi, H, W, &rp));
             } else {  // Phase6 of iteration n - 1 with the phi of iteration n folded in (the main chain's Phase6 was
                       // opened by its solver's end mark)
-                PAPOF_TRY(update_warp_phi(h, B.sp, u, v, ua, va, f1, f2, warp, last ? nullptr : B.phi, H, W, fc, !last,
+                double* const wu = last && out_u && out_v ? out_u : ua;
+                double* const wv = last && out_u && out_v ? out_v : va;
+                PAPOF_TRY(update_warp_phi(h, B.sp, u, v, wu, wv, f1, f2, warp, last ? nullptr : B.phi, H, W, fc, !last,
                                           ru.y0, ru.y1));
-                un = ua;
-                vn = va;
+                un = wu;
+                vn = wv;
             }
             if (!last) {
                 if (crit) clk.phase(PAPOF_T_PHASE1_GENERATE);
@@ -488,13 +503,17 @@ int smooth_flow_strips(papof_handle* h, const StripSchedule& q, const LevelInit&
             if (!last) {
                 h->sor_mark = crit ? +sor_on_main : +sor_on_strip;
                 h->sor_mark_ctx = crit ? &clk : &uclk;
-                const int rc = sor_solve_bands(h, B.sp, H, W, alpha, omega, n_sor, n, q.beta[i0], q.beta[i1]);
+                const int rc = sor_solve_bands(h, B.sp, H, W, alpha, omega, n_sor, prog + (size_t)n * prog_per_solve,
+                                               q.beta[i0], q.beta[i1]);
                 h->sor_mark = nullptr;
                 h->sor_mark_ctx = nullptr;
                 PAPOF_TRY(rc);
             }
         }
-        if (n > 0) {
+        if (n == n_outer && out_u && out_v) {
+            u = out_u;
+            v = out_v;
+        } else if (n > 0) {
             std::swap(u, ua);
             std::swap(v, va);
         }
@@ -730,6 +749,32 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         }
     }
 
+    // Exact-order path: the progress counters of EVERY solve of the call are cleared at once on the preparation stream (one
+    // fill instead of one per solve in front of each solver launch on the main stream).  [Also tried: one set of coefficient
+    // planes per level, zeroed ahead on the preparation stream instead of sor_reset_planes() on the main stream at the start
+    // of each level -- 0.2 ms SLOWER per 1080p pair (same-box A/B 11.83 vs 11.62 ms, all of it in the solver kernels): the
+    // fills in front of a level leave the planes in the Infinity Cache, exactly as the (du, dv) clear in front of a solve.]
+    struct LevelCounters {
+        size_t prog_off = 0, prog_per = 0;  // offset (unsigneds) of the level's first solve, stride per solve
+    };
+    std::vector<LevelCounters> LP(levels);
+    size_t prog_total = 0;
+    const bool exact = P.sor_mode == PAPOF_SOR_EXACT;
+    if (exact) {
+        for (int k = 0; k < levels; k++) {
+            LP[k].prog_per = sor_counters_words(L[k].h, L[k].w, P.n_sor + k * P.n_sor_per_level);
+            LP[k].prog_off = prog_total;
+            prog_total += LP[k].prog_per * (size_t)((P.n_outer + k * P.n_outer_per_level) * P.n_inner);
+        }
+        if (!in_capture) {
+            const int rc_c = sor_counters_ensure(h, prog_total);
+            if (rc_c != PAPOF_OK) return rc_c;
+        } else if (prog_total + 64 > h->sync_cap) {  // the eager call before the capture sized them
+            abandon_capture();
+            return PAPOF_EDEVICE;
+        }
+    }
+
     const bool overlap = h->overlap_prep && P.phase_timing != 1 && h->prep_stream != nullptr;
     hipStream_t const main_stream = h->stream, prep = overlap ? h->prep_stream : h->stream;
     while (h->sync_events.size() < (size_t)levels + 2) {
@@ -745,6 +790,8 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     };
     const auto prepare = [&]() -> int {
         StreamSwap on_prep(h, prep);
+        pclk.phase(PAPOF_T_ALLOCATION);  // the reference's buffers are zero-filled when they are allocated (src/Image.h:518-532)
+        if (exact && !sor_counters_clear(h, 0, prog_total)) return PAPOF_EDEVICE;
         pclk.phase(PAPOF_T_CONSTRUCTION);  // src/OpticalFlow.cpp:757-758 (and the wrapper's copies, Coarse2FineFlowWrapper.cpp:23-28)
         if (op != kSeqNext) PAPOF_TRY(load_frame(h, fa, L[0].p1, H, W, C));
         PAPOF_TRY(load_frame(h, fb, L[0].p2, H, W, C));
@@ -821,7 +868,12 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
             clk.phase(PAPOF_T_ALLOCATION);  // flow up-sampling and first warp of the level (:801-814)
             const double *f1 = F1[k], *f2 = F2[k];
             const int n_sor_k = P.n_sor + k * P.n_sor_per_level, n_outer_k = P.n_outer + k * P.n_outer_per_level;
+            unsigned* prog_k = nullptr;
+            if (exact) prog_k = h->sync_words + 32 + LP[k].prog_off;  // this level's counters, cleared by the preparation stream
             PAPOF_TRY(sor_bind(h, B.sp, lh, lw, n_sor_k));
+            // the level's result goes straight to the caller's buffers on the finest level
+            double* const out_u = k == 0 ? d_vx : nullptr;
+            double* const out_v = k == 0 ? d_vy : nullptr;
             // strips (smooth_flow_strips): big levels of the exact-order path, default branches, overlapping streams allowed
             StripSchedule sch;
             // OFF by default (PAPOF_STRIPS=2..4 enables): measured slower on every level it applies to
@@ -859,10 +911,11 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
             PAPOF_TRY(sor_reset_planes(h, B.sp));
             if (strips)
                 PAPOF_TRY(smooth_flow_strips(h, sch, li, f1, f2, warp, u, v, u2, v2, lh, lw, fc, P.alpha, n_sor_k, P.omega, B,
-                                             clk, uclk, S1[k]));
+                                             clk, uclk, S1[k], prog_k, LP[k].prog_per, out_u, out_v));
             else
                 PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, u2, v2, lh, lw, fc, P.alpha, n_outer_k, P.n_inner, n_sor_k,
-                                      P.omega, P.sor_mode, B, clk, S1[k], false));
+                                      P.omega, P.sor_mode, B, clk, S1[k], false, prog_k, exact ? LP[k].prog_per : 0, out_u,
+                                      out_v));
             pw = lw;
             ph = lh;
         }
@@ -870,8 +923,8 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         if (overlap) PAPOF_HIP(hipStreamWaitEvent(main_stream, h->sync_events[levels], 0));
         clk.phase(PAPOF_T_POSTPROCESSING);  // src/OpticalFlow.cpp:841-842
         PAPOF_TRY(bicubic_warp(h, L[0].p1, L[0].p2, gx, gy, gxy, u, v, d_warp, H, W, C));
-        PAPOF_HIP(hipMemcpyAsync(d_vx, u, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        PAPOF_HIP(hipMemcpyAsync(d_vy, v, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (u != d_vx) PAPOF_HIP(hipMemcpyAsync(d_vx, u, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (v != d_vy) PAPOF_HIP(hipMemcpyAsync(d_vy, v, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         return PAPOF_OK;
     };
     rc_main = solve_levels();
@@ -1943,7 +1996,7 @@ int papof_test_sor_strips(papof_handle* h, int height, int width, int n_sor, int
         PAPOF_HIP(hipEventRecord(ev, main_stream));
         PAPOF_HIP(hipStreamWaitEvent(top, ev, 0));
         h->stream = top;
-        int rc = sor_solve_bands(h, sp, height, width, 0.012, 1.8, n_sor, 0, 0, split_band);
+        int rc = sor_solve_bands(h, sp, height, width, 0.012, 1.8, n_sor, h->sync_words + 32, 0, split_band);
         h->stream = main_stream;
         PAPOF_TRY(rc);
         if (delay_us > 0) {  // the lower strip starts later, as behind its own assembly kernels
@@ -1951,7 +2004,7 @@ int papof_test_sor_strips(papof_handle* h, int height, int width, int n_sor, int
             const double t0 = wall();
             while ((wall() - t0) * 1e6 < delay_us) {}
         }
-        PAPOF_TRY(sor_solve_bands(h, sp, height, width, 0.012, 1.8, n_sor, 0, split_band, sp.sd.nb));
+        PAPOF_TRY(sor_solve_bands(h, sp, height, width, 0.012, 1.8, n_sor, h->sync_words + 32, split_band, sp.sd.nb));
         PAPOF_HIP(hipStreamSynchronize(top));
         PAPOF_HIP(hipStreamSynchronize(main_stream));
         PAPOF_TRY(sor_check(h));

@@ -256,6 +256,7 @@ struct papof_handle {
     int rb_shape = 0;                // ... region shape 1..4 (sor.hip: blocked_shape); 0 = by plane size
     int rb_naive = 0;                // 1: one launch per half-sweep on the planes (cross-check)
     int sor_resident = 0;            // tasks per launch of the exact-order kernels; 0 = 8 per CU (sor.hip: resident_tasks)
+    unsigned* sor_prog_next = nullptr;  // cleared progress counters for the NEXT sor_solve() (else it clears its own)
     int sor_launches = 0;            // exact-order solver kernels launched by the current / last call (measurement: bench.py)
     double sor_upper_sec = 0.0;      // ... of which: event time of the launches on the strip streams (added to Phase5_SOR)
     // strips (api.hip: smooth_flow_strips): a level's plane as S horizontal strips of solver bands, each on its own
@@ -356,7 +357,11 @@ int sor_check(papof_handle* h);  // after a stream sync: PAPOF_ETIMEOUT if a dev
 bool sor_strips_supported(const papof_handle* h, const SorPlanes& sp, int n_sor);
 int sor_strips_begin(papof_handle* h, const SorPlanes& sp, int n_sor, int n_solves);
 int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor,
-                    int solve_idx, int b0, int b1);
+                    unsigned* prog, int b0, int b1);
+// progress counters cleared ahead of the solves that use them (flow_device: all of a call's, on the preparation stream)
+size_t sor_counters_words(int H, int W, int n_sor);
+int sor_counters_ensure(papof_handle* h, size_t words);
+unsigned* sor_counters_clear(papof_handle* h, size_t offset_words, size_t words);
 int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes& sp);  // carve the operand planes
 int sor_bind(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor);  // choose the layout of the next solves (skew mode)
 int sor_group_size(const papof_handle* h, int H, int W, int n_sor);   // sweeps per workgroup the solver will use

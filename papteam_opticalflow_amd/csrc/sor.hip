@@ -1810,10 +1810,17 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             h->sync_cap = cap;
             PAPOF_HIP(hipMemsetAsync(h->sync_words, 0, cap * sizeof(unsigned), h->stream));
         }
-        // first line: abort word (kept across solves; checked by sor_check); counters start at the second line
+        // first line: abort word (kept across solves; checked by sor_check); counters start at the second line.  The
+        // orchestrator may hand over counters it has cleared already (flow_device clears those of every solve of a call
+        // on the preparation stream: sor_counters_*), else this solve's are cleared here
         unsigned* prog = h->sync_words + kProgStride;
-        const size_t nbytes = (size_t)sd.nb * n_sor * kProgStride * sizeof(unsigned);
-        PAPOF_HIP(hipMemsetAsync(prog, 0, nbytes, h->stream));
+        if (h->sor_prog_next) {
+            prog = h->sor_prog_next;
+            h->sor_prog_next = nullptr;
+        } else {
+            const size_t nbytes = (size_t)sd.nb * n_sor * kProgStride * sizeof(unsigned);
+            PAPOF_HIP(hipMemsetAsync(prog, 0, nbytes, h->stream));
+        }
         ExactArgs A;
         A.phi = sp.phi;
         A.xy = sp.xy;  // paired planes: only phi / a1 / b1 / du are used as the four plane bases
@@ -2034,38 +2041,58 @@ bool sor_strips_supported(const papof_handle* h, const SorPlanes& sp, int n_sor)
     return tasks <= resident_tasks(h);  // one launch per strip: every task of the solve resident
 }
 
-int sor_strips_begin(papof_handle* h, const SorPlanes& sp, int n_sor, int n_solves) {
+// Counters of one solve of a height x width plane (whichever layout sor_bind() picks), in unsigneds
+size_t sor_counters_words(int H, int W, int n_sor) {
+    const int nb = std::max(skew_dims(H, W, n_sor, 1, 1).nb, skew_dims(H, W, n_sor, 1, 2).nb);
+    return (size_t)nb * n_sor * kProgStride;
+}
+
+// Room for `words` unsigneds of counters behind the abort line (may reallocate: call it before anything is enqueued)
+int sor_counters_ensure(papof_handle* h, size_t words) {
+    const size_t need = words + kProgStride;
+    if (need <= h->sync_cap) return PAPOF_OK;
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    if (h->sync_words) PAPOF_HIP(hipFree(h->sync_words));
+    h->sync_words = nullptr;
+    h->sync_cap = 0;
+    const size_t cap = (need + 1023) & ~size_t(1023);
+    PAPOF_HIP(hipMalloc((void**)&h->sync_words, cap * sizeof(unsigned)));
+    h->sync_cap = cap;
+    PAPOF_HIP(hipMemsetAsync(h->sync_words, 0, cap * sizeof(unsigned), h->stream));
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    return PAPOF_OK;
+}
+
+// Clear `words` unsigneds of counters (on h->stream); returns their base: solve i of a level uses base + i * per_solve
+unsigned* sor_counters_clear(papof_handle* h, size_t offset_words, size_t words) {
+    if (offset_words + words + kProgStride > h->sync_cap) return nullptr;
+    unsigned* base = h->sync_words + kProgStride + offset_words;
+    if (hipMemsetAsync(base, 0, words * sizeof(unsigned), h->stream) != hipSuccess) return nullptr;
+    return base;
+}
+
+int sor_strips_begin(papof_handle* h, const SorPlanes& sp, int n_sor, int n_solves) {  // the test aid's (api.hip)
     const SkewDims& sd = sp.sd;
-    const size_t per = (size_t)sd.nb * n_sor * kProgStride, words = per * n_solves + kProgStride;
-    if (words > h->sync_cap) {
-        PAPOF_HIP(hipStreamSynchronize(h->stream));
-        if (h->sync_words) PAPOF_HIP(hipFree(h->sync_words));
-        h->sync_words = nullptr;
-        h->sync_cap = 0;
-        const size_t cap = (words + 1023) & ~size_t(1023);
-        PAPOF_HIP(hipMalloc((void**)&h->sync_words, cap * sizeof(unsigned)));
-        h->sync_cap = cap;
-        PAPOF_HIP(hipMemsetAsync(h->sync_words, 0, cap * sizeof(unsigned), h->stream));
-    } else {
-        PAPOF_HIP(hipMemsetAsync(h->sync_words + kProgStride, 0, per * n_solves * sizeof(unsigned), h->stream));
-    }
-    if (std::getenv("PAPOF_SOR_INJECT_ABORT"))  // fault injection for the tests, as in sor_solve
-        PAPOF_HIP(hipMemsetAsync(h->sync_words, 1, sizeof(unsigned), h->stream));
+    const size_t per = (size_t)sd.nb * n_sor * kProgStride;
+    PAPOF_TRY(sor_counters_ensure(h, per * n_solves));
+    if (!sor_counters_clear(h, 0, per * n_solves)) return PAPOF_EDEVICE;
     return PAPOF_OK;
 }
 
 int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor,
-                    int solve_idx, int b0, int b1) {
+                    unsigned* prog, int b0, int b1) {
     if (!sp.skew || n_sor <= 0) return PAPOF_EINVAL;
     const SkewDims sd = skew_dims(H, W, n_sor, sp.sd.group, sp.sd.fuse);
     if (sd.fuse != sp.sd.fuse || sd.hp != sp.sd.hp || sd.npos != sp.sd.npos || sd.qt != sp.sd.qt || sd.nb != sp.sd.nb ||
         sd.n_sor != sp.sd.n_sor || sd.n > sp.cap_cells || sd.nd + sd.nh > sp.cap_cells_d || sd.group > 1)
         return PAPOF_EINVAL;
     if ((sd.n + kLanes) * 16 >= (size_t(1) << 30) || (sd.nd + sd.nh) * 16 >= (size_t(1) << 30)) return PAPOF_EINVAL;
-    if (b0 < 0 || b1 > sd.nb || b1 <= b0 || solve_idx < 0) return PAPOF_EINVAL;
+    if (b0 < 0 || b1 > sd.nb || b1 <= b0 || !prog) return PAPOF_EINVAL;
     const size_t per = (size_t)sd.nb * n_sor * kProgStride;
-    if (per * (solve_idx + 1) + kProgStride > h->sync_cap) return PAPOF_EINVAL;  // sor_strips_begin() sized the counters
+    if (prog < h->sync_words + kProgStride || prog + per > h->sync_words + h->sync_cap) return PAPOF_EINVAL;
     const int nbl = b1 - b0;
+    if (std::getenv("PAPOF_SOR_INJECT_ABORT"))  // fault injection for the tests, as in sor_solve
+        PAPOF_HIP(hipMemsetAsync(h->sync_words, 1, sizeof(unsigned), h->stream));
     {
         const unsigned n16 = (unsigned)(2 * sd.npos_d) * (unsigned)nbl * kLanes;
         hipLaunchKernelGGL(k_sor_clear_bands, dim3((n16 + 255) / 256), dim3(256), 0, h->stream, (uint4*)sp.du, sd.nb, b0,
@@ -2080,7 +2107,7 @@ int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double a
     A.b2 = sp.b2;
     A.du = sp.du;
     A.dv = sp.dv;
-    A.prog = h->sync_words + kProgStride + per * solve_idx;
+    A.prog = prog;
     A.abort = h->sync_words;
     A.H = H;
     A.W = W;
