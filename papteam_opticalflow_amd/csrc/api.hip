@@ -183,16 +183,25 @@ int pyramid_plan(int H, int W, double ratio, int nlev, std::vector<Level>& L, st
     return PAPOF_OK;
 }
 
+// One pyramid level from its source level: GaussianSmoothing + imresize (src/GaussianPyramid.cpp:97-99, :103-105).  Both
+// filter passes are one launch; a half-width of 0 (level 1 at ratio 0.75: sigma * 3 truncates to 0) makes the
+// smoothing the identity -- a single tap of exactly 1.0 accumulated from 0.0 -- and the resize reads the source directly
+// (the resize accumulates from +0.0 as well, so not even the sign of a zero can differ).
+int smooth_and_resize(papof_handle* h, const double* src, double* dst, double* tmp_a, double* tmp_b, const PyrPlan& p, int C,
+                      int dh, int dw) {
+    const Taps g = gaussian_taps(p.sigma, p.fsize);
+    if (g.fsize == 0 && g.t[0] == 1.0) return resize(h, src, dst, p.sh, p.sw, C, dh, dw, p.rate, p.rate, false, 0.0);
+    PAPOF_TRY(filter_hv(h, src, tmp_b, tmp_a, p.sh, p.sw, C, g, g));
+    return resize(h, tmp_b, dst, p.sh, p.sw, C, dh, dw, p.rate, p.rate, false, 0.0);
+}
+
 int build_pyramid(papof_handle* h, const std::vector<Level>& L, const std::vector<PyrPlan>& plan, int C, bool second,
                   double* tmp_a, double* tmp_b) {
     for (size_t i = 1; i < L.size(); i++) {
         const PyrPlan& p = plan[i];
         const double* src = second ? L[p.src_level].p2 : L[p.src_level].p1;
         double* dst = second ? L[i].p2 : L[i].p1;
-        const Taps g = gaussian_taps(p.sigma, p.fsize);
-        PAPOF_TRY(filter_h(h, src, tmp_a, p.sh, p.sw, C, g));
-        PAPOF_TRY(filter_v(h, tmp_a, tmp_b, p.sh, p.sw, C, g));
-        PAPOF_TRY(resize(h, tmp_b, dst, p.sh, p.sw, C, L[i].h, L[i].w, p.rate, p.rate, false, 0.0));
+        PAPOF_TRY(smooth_and_resize(h, src, dst, tmp_a, tmp_b, p, C, L[i].h, L[i].w));
     }
     return PAPOF_OK;
 }
@@ -272,8 +281,7 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
     const double* im1s = im1s_ready;  // smoothed frame 1: constant within the level (prepared ahead by flow_device)
     if (!im1s) {
         clk.phase(PAPOF_T_PHASE1_GENERATE);
-        PAPOF_TRY(filter_h(h, f1, B.tmp, H, W, fc, g));
-        PAPOF_TRY(filter_v(h, B.tmp, B.im1s, H, W, fc, g));
+        PAPOF_TRY(filter_hv(h, f1, B.im1s, B.tmp, H, W, fc, g, g));
         im1s = B.im1s;
     }
     for (int count = 0; count < n_outer; count++) {
@@ -803,13 +811,10 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         const auto build_level = [&](int i) -> int {
             if (i == 0) return PAPOF_OK;
             const PyrPlan& q = plan[i];
-            const Taps g = gaussian_taps(q.sigma, q.fsize);
             for (int second = (op == kSeqNext ? 1 : 0); second < 2; second++) {
                 const double* src = second ? L[q.src_level].p2 : L[q.src_level].p1;
                 double* dst = second ? L[i].p2 : L[i].p1;
-                PAPOF_TRY(filter_h(h, src, tmp_a, q.sh, q.sw, C, g));
-                PAPOF_TRY(filter_v(h, tmp_a, tmp_b, q.sh, q.sw, C, g));
-                PAPOF_TRY(resize(h, tmp_b, dst, q.sh, q.sw, C, L[i].h, L[i].w, q.rate, q.rate, false, 0.0));
+                PAPOF_TRY(smooth_and_resize(h, src, dst, tmp_a, tmp_b, q, C, L[i].h, L[i].w));
             }
             return PAPOF_OK;
         };
@@ -824,8 +829,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
             PAPOF_TRY(im2feature(h, L[k].p1, F1[k], L[k].h, L[k].w, C));
             PAPOF_TRY(im2feature(h, L[k].p2, F2[k], L[k].h, L[k].w, C));
             pclk.phase(PAPOF_T_PHASE1_GENERATE);  // smoothing of frame 1: first half of getDxs (:84-90)
-            PAPOF_TRY(filter_h(h, F1[k], prep_tmp, L[k].h, L[k].w, fc, g5));
-            PAPOF_TRY(filter_v(h, prep_tmp, S1[k], L[k].h, L[k].w, fc, g5));
+            PAPOF_TRY(filter_hv(h, F1[k], S1[k], prep_tmp, L[k].h, L[k].w, fc, g5, g5));
             pclk.phase(-1);
             if (overlap) PAPOF_HIP(hipEventRecord(h->sync_events[k], prep));
         }
@@ -1070,7 +1074,19 @@ int papof_create(int device, papof_handle** out) {
         delete h;
         return PAPOF_ENODEVICE;
     }
-    if ((e = hipStreamCreateWithFlags(&h->prep_stream, hipStreamNonBlocking)) != hipSuccess) {
+    // The preparation stream may be confined to a share of the CUs (PAPOF_PREP_CUS = number of CUs; the mask's bits are
+    // dealt round-robin over the XCDs): its streaming kernels then take longer, still hidden behind the coarse levels'
+    // solves, but load the memory system less -- those latency-bound solves run 0.6 ms per 1080p pair slower beside an
+    // unconfined preparation stream than alone (same-box A/B).
+    int prep_cus = 0;
+    if (const char* cs = std::getenv("PAPOF_PREP_CUS")) prep_cus = std::atoi(cs);
+    if (prep_cus > 0 && prep_cus < h->cu_count) {
+        uint32_t mask[16] = {0};
+        for (int i = 0; i < prep_cus && i < 512; i++) mask[i / 32] |= 1u << (i % 32);
+        e = hipExtStreamCreateWithCUMask(&h->prep_stream, (uint32_t)((h->cu_count + 31) / 32), mask);
+        if (e != hipSuccess) h->prep_stream = nullptr;  // fall back to an ordinary stream
+    }
+    if (!h->prep_stream && (e = hipStreamCreateWithFlags(&h->prep_stream, hipStreamNonBlocking)) != hipSuccess) {
         set_last_error("hipStreamCreate", e, __FILE__, __LINE__);
         papof_destroy(h);
         return PAPOF_ENODEVICE;

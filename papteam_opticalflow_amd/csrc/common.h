@@ -304,6 +304,8 @@ int filter_h(papof_handle* h, const double* src, double* dst, int H, int W, int 
              const Rect* rc = nullptr);
 int filter_v(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f,
              const Rect* rc = nullptr);
+int filter_hv(papof_handle* h, const double* src, double* dst, double* tmp, int H, int W, int planes, const Taps& fh,
+              const Taps& fv);  // both passes in one launch (same bits); `tmp` only for half-widths beyond the fused kernel's
 int resize(papof_handle* h, const double* src, double* dst, int sh, int sw, int planes, int dh, int dw, double xr,
            double yr, bool use_post, double post, const Rect* rc = nullptr);
 int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C);

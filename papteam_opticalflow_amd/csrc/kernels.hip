@@ -84,6 +84,36 @@ __global__ void k_filter_v(const double* __restrict__ src, double* __restrict__ 
     dst[blockIdx.z * np + (size_t)i * W + j] = acc;
 }
 
+// Both passes of a separable filter in ONE kernel (h pass into LDS, v pass out of it): the operations and their order
+// are those of k_filter_h followed by k_filter_v -- the v pass reads the h-filtered values of the rows clamp(i + l), here
+// rows of the block's LDS image -- so the bits are the same, but the h-filtered plane never goes to HBM (2.4 instead of
+// 4 plane transfers at half-width 3).  A block owns kHvRows rows x 64 columns of one plane.
+constexpr int kHvRows = 32, kHvMaxF = 4;
+__global__ __launch_bounds__(256) void k_filter_hv(const double* __restrict__ src, double* __restrict__ dst, int H, int W,
+                                                   Taps fh, Taps fv) {
+    __shared__ double hs[kHvRows + 2 * kHvMaxF][BX];
+    const int j = blockIdx.x * BX + threadIdx.x, i0 = blockIdx.y * kHvRows, f = fv.fsize;
+    const size_t np = (size_t)H * W;
+    const double* plane = src + blockIdx.z * np;
+    if (j < W) {
+        for (int r = threadIdx.y; r < kHvRows + 2 * f; r += BY) {
+            const double* row = plane + (size_t)clampi(i0 + r - f, H) * W;
+            double acc = 0.0;
+            for (int l = -fh.fsize; l <= fh.fsize; l++) acc += row[clampi(j + l, W)] * fh.t[l + fh.fsize];
+            hs[r][threadIdx.x] = acc;
+        }
+    }
+    __syncthreads();
+    if (j >= W) return;
+    for (int r = threadIdx.y; r < kHvRows; r += BY) {
+        const int i = i0 + r;
+        if (i >= H) break;
+        double acc = 0.0;
+        for (int l = -f; l <= f; l++) acc += hs[r + l + f][threadIdx.x] * fv.t[l + f];
+        dst[blockIdx.z * np + (size_t)i * W + j] = acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // bilinear sampling: src/ImageProcessing.h:138-157.  Integer part by truncation toward zero,
 // fraction clamped to [0,1], taps visited x-offset outer / y-offset inner and ACCUMULATED from 0.
@@ -968,6 +998,20 @@ int filter_v(papof_handle* h, const double* src, double* dst, int H, int W, int 
     const Rect r = region(rc, W, H);
     if (r.empty()) return PAPOF_OK;
     hipLaunchKernelGGL(k_filter_v, grid2d(r, planes), dim3(BX, BY), 0, h->stream, src, dst, H, W, f, r);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+// dst = v-filter(h-filter(src)) in one launch when both half-widths fit the fused kernel, else through `tmp` (two passes)
+int filter_hv(papof_handle* h, const double* src, double* dst, double* tmp, int H, int W, int planes, const Taps& fh,
+              const Taps& fv) {
+    if (fh.fsize > kHvMaxF || fv.fsize > kHvMaxF) {
+        if (!tmp) return PAPOF_EINVAL;
+        PAPOF_TRY(filter_h(h, src, tmp, H, W, planes, fh));
+        return filter_v(h, tmp, dst, H, W, planes, fv);
+    }
+    hipLaunchKernelGGL(k_filter_hv, dim3((W + BX - 1) / BX, (H + kHvRows - 1) / kHvRows, planes), dim3(BX, BY), 0, h->stream,
+                       src, dst, H, W, fh, fv);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
