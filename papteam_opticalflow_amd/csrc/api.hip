@@ -256,10 +256,7 @@ int alloc_branch_buffers(papof_handle* h, Arena& A, int H, int W, int fc, int in
 
 // derivative planes {-.5, 0, .5} of the frame-2 features of a level (Image::warpImageBicubicRef, src/Image.h:2587-2595)
 int bicubic_planes(papof_handle* h, const double* f2, int H, int W, int fc, SolveBuffers& B) {
-    const Taps c3 = central3_taps();
-    PAPOF_TRY(filter_h(h, f2, B.bgx, H, W, fc, c3));
-    PAPOF_TRY(filter_v(h, f2, B.bgy, H, W, fc, c3));
-    PAPOF_TRY(filter_v(h, B.bgx, B.bgxy, H, W, fc, c3));
+    PAPOF_TRY(central3_planes(h, f2, B.bgx, B.bgy, B.bgxy, H, W, fc));
     return PAPOF_OK;
 }
 
@@ -834,10 +831,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
             if (overlap) PAPOF_HIP(hipEventRecord(h->sync_events[k], prep));
         }
         pclk.phase(PAPOF_T_POSTPROCESSING);  // derivative planes of the final bicubic warp (src/Image.h:2590-2594)
-        const Taps c3 = central3_taps();
-        PAPOF_TRY(filter_h(h, L[0].p2, gx, H, W, C, c3));
-        PAPOF_TRY(filter_v(h, L[0].p2, gy, H, W, C, c3));
-        PAPOF_TRY(filter_v(h, gx, gxy, H, W, C, c3));
+        PAPOF_TRY(central3_planes(h, L[0].p2, gx, gy, gxy, H, W, C));
         pclk.phase(-1);
         if (overlap) PAPOF_HIP(hipEventRecord(h->sync_events[levels], prep));
         return PAPOF_OK;
@@ -1861,10 +1855,7 @@ int papof_stage_bicubic_warp_ex(papof_handle* h, const double* im1, const double
     double* fy = S.up_planar(vy, height, width, 1);
     double *gx = S.dev(n), *gy = S.dev(n), *gxy = S.dev(n), *o = S.dev(n);
     PAPOF_TRY(S.rc);
-    const Taps c3 = central3_taps();
-    PAPOF_TRY(filter_h(h, b, gx, height, width, c, c3));
-    PAPOF_TRY(filter_v(h, b, gy, height, width, c, c3));
-    PAPOF_TRY(filter_v(h, gx, gxy, height, width, c, c3));
+    PAPOF_TRY(central3_planes(h, b, gx, gy, gxy, height, width, c));
     PAPOF_TRY(bicubic_warp(h, a, b, gx, gy, gxy, fx, fy, o, height, width, c, nullptr, false, clamp != 0));
     PAPOF_HIP(hipMemcpyAsync(out, o, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     PAPOF_HIP(hipStreamSynchronize(h->stream));

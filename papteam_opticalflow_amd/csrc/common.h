@@ -309,6 +309,7 @@ int filter_hv(papof_handle* h, const double* src, double* dst, double* tmp, int 
 int resize(papof_handle* h, const double* src, double* dst, int sh, int sw, int planes, int dh, int dw, double xr,
            double yr, bool use_post, double post, const Rect* rc = nullptr);
 int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C);
+int central3_planes(papof_handle* h, const double* src, double* gx, double* gy, double* gxy, int H, int W, int planes);
 int warp_bilinear(papof_handle* h, const double* im1, const double* im2, const double* vx, const double* vy,
                   double* out, int H, int W, int planes, const Rect* rc = nullptr);
 int smooth_v_blend(papof_handle* h, const double* tmp, const double* im1s, double* blend, double* imdt, int H,

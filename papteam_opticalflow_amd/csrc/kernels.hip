@@ -197,6 +197,71 @@ __global__ void k_im2feature(const double* __restrict__ im, double* __restrict__
     }
 }
 
+// The same through an LDS tile of gray values (one-GPU path): a block owns kFeatRows rows x 64 columns, evaluates gray
+// ONCE per cell of the tile grown by the 5-tap filters' reach (same expression: same bits) and takes the two derivative
+// sums out of LDS in the same order -- 4 instead of 27 cached loads per pixel.
+constexpr int kFeatRows = 16;
+template <int C>
+__global__ __launch_bounds__(256) void k_im2feature_tiled(const double* __restrict__ im, double* __restrict__ feat, int H,
+                                                          int W, Taps d) {
+    __shared__ double g[kFeatRows + 4][BX + 4];
+    const int j0 = blockIdx.x * BX, i0 = blockIdx.y * kFeatRows;
+    const size_t np = (size_t)H * W;
+    for (int c = threadIdx.y * BX + threadIdx.x; c < (kFeatRows + 4) * (BX + 4); c += BX * BY) {
+        const int r = c / (BX + 4), cc = c - r * (BX + 4);
+        g[r][cc] = gray_at<C>(im, np, (size_t)clampi(i0 + r - 2, H) * W + clampi(j0 + cc - 2, W));
+    }
+    __syncthreads();
+    const int j = j0 + threadIdx.x;
+    if (j >= W) return;
+    for (int r = threadIdx.y; r < kFeatRows; r += BY) {
+        const int i = i0 + r;
+        if (i >= H) break;
+        const size_t o = (size_t)i * W + j;
+        double gx = 0.0, gy = 0.0;
+#pragma unroll
+        for (int l = -2; l <= 2; l++) gx += g[r + 2][threadIdx.x + 2 + l] * d.t[l + 2];
+#pragma unroll
+        for (int l = -2; l <= 2; l++) gy += g[r + 2 + l][threadIdx.x + 2] * d.t[l + 2];
+        feat[o] = g[r + 2][threadIdx.x + 2];
+        feat[np + o] = gx;
+        feat[2 * np + o] = gy;
+        if (C == 3) {
+            const double gg = im[np + o];
+            feat[3 * np + o] = gg - im[o];
+            feat[4 * np + o] = gg - im[2 * np + o];
+        }
+    }
+}
+
+// The three derivative planes of the final bicubic warp in one launch (Image::warpImageBicubicRef, src/Image.h:2590-2594:
+// imfilter_h, imfilter_v, imfilter_v of the first with {-.5, 0, .5}): gx, gy as k_filter_h / k_filter_v compute them,
+// gxy = the v pass over gx, whose three rows are recomputed here with the h pass's own operations (same bits).
+__global__ void k_central3_all(const double* __restrict__ src, double* __restrict__ gx, double* __restrict__ gy,
+                               double* __restrict__ gxy, int H, int W, Taps c3) {
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    if (j >= W || i >= H) return;
+    const size_t np = (size_t)H * W;
+    const double* p = src + blockIdx.z * np;
+    const auto hrow = [&](int ii) {
+        const double* row = p + (size_t)ii * W;
+        double acc = 0.0;
+#pragma unroll
+        for (int l = -1; l <= 1; l++) acc += row[clampi(j + l, W)] * c3.t[l + 1];
+        return acc;
+    };
+    const double hx[3] = {hrow(clampi(i - 1, H)), hrow(i), hrow(clampi(i + 1, H))};
+    double vy = 0.0, vxy = 0.0;
+#pragma unroll
+    for (int l = -1; l <= 1; l++) vy += p[(size_t)clampi(i + l, H) * W + j] * c3.t[l + 1];
+#pragma unroll
+    for (int l = -1; l <= 1; l++) vxy += hx[l + 1] * c3.t[l + 1];
+    const size_t o = blockIdx.z * np + (size_t)i * W + j;
+    gx[o] = hx[1];
+    gy[o] = vy;
+    gxy[o] = vxy;
+}
+
 // ------------------------------------------------------------------------------------------------
 // OpticalFlow::warpFL -> ImageProcessing::warpImage, src/ImageProcessing.h:483-503.
 // ------------------------------------------------------------------------------------------------
@@ -1002,6 +1067,13 @@ int filter_v(papof_handle* h, const double* src, double* dst, int H, int W, int 
     return PAPOF_OK;
 }
 
+int central3_planes(papof_handle* h, const double* src, double* gx, double* gy, double* gxy, int H, int W, int planes) {
+    hipLaunchKernelGGL(k_central3_all, grid2d(W, H, planes), dim3(BX, BY), 0, h->stream, src, gx, gy, gxy, H, W,
+                       central3_taps());
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
 // dst = v-filter(h-filter(src)) in one launch when both half-widths fit the fused kernel, else through `tmp` (two passes)
 int filter_hv(papof_handle* h, const double* src, double* dst, double* tmp, int H, int W, int planes, const Taps& fh,
               const Taps& fv) {
@@ -1028,9 +1100,11 @@ int resize(papof_handle* h, const double* src, double* dst, int sh, int sw, int 
 
 int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C) {
     if (C == 3) {
-        hipLaunchKernelGGL(k_im2feature<3>, grid2d(W, H), dim3(BX, BY), 0, h->stream, im, feat, H, W, deriv5_taps());
+        hipLaunchKernelGGL(k_im2feature_tiled<3>, dim3((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows), dim3(BX, BY), 0,
+                           h->stream, im, feat, H, W, deriv5_taps());
     } else if (C == 1) {
-        hipLaunchKernelGGL(k_im2feature<1>, grid2d(W, H), dim3(BX, BY), 0, h->stream, im, feat, H, W, deriv5_taps());
+        hipLaunchKernelGGL(k_im2feature_tiled<1>, dim3((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows), dim3(BX, BY), 0,
+                           h->stream, im, feat, H, W, deriv5_taps());
     } else {  // src/OpticalFlow.cpp:956-957: any other channel count is passed through
         PAPOF_HIP(hipMemcpyAsync(feat, im, sizeof(double) * (size_t)H * W * C, hipMemcpyDeviceToDevice, h->stream));
         return PAPOF_OK;
