@@ -89,17 +89,20 @@ __global__ void k_filter_v(const double* __restrict__ src, double* __restrict__ 
 // rows of the block's LDS image -- so the bits are the same, but the h-filtered plane never goes to HBM (2.4 instead of
 // 4 plane transfers at half-width 3).  A block owns kHvRows rows x 64 columns of one plane.
 constexpr int kHvRows = 32, kHvMaxF = 4;
+template <int F>  // F = the half-width of both passes as a compile-time constant (fully unrolled tap loops), or -1: run time
 __global__ __launch_bounds__(256) void k_filter_hv(const double* __restrict__ src, double* __restrict__ dst, int H, int W,
                                                    Taps fh, Taps fv) {
     __shared__ double hs[kHvRows + 2 * kHvMaxF][BX];
-    const int j = blockIdx.x * BX + threadIdx.x, i0 = blockIdx.y * kHvRows, f = fv.fsize;
+    const int j = blockIdx.x * BX + threadIdx.x, i0 = blockIdx.y * kHvRows;
+    const int f = F >= 0 ? F : fv.fsize, fx = F >= 0 ? F : fh.fsize;
     const size_t np = (size_t)H * W;
     const double* plane = src + blockIdx.z * np;
     if (j < W) {
         for (int r = threadIdx.y; r < kHvRows + 2 * f; r += BY) {
             const double* row = plane + (size_t)clampi(i0 + r - f, H) * W;
             double acc = 0.0;
-            for (int l = -fh.fsize; l <= fh.fsize; l++) acc += row[clampi(j + l, W)] * fh.t[l + fh.fsize];
+#pragma unroll
+            for (int l = -fx; l <= fx; l++) acc += row[clampi(j + l, W)] * fh.t[l + fx];
             hs[r][threadIdx.x] = acc;
         }
     }
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256) void k_filter_hv(const double* __restrict__ sr
         const int i = i0 + r;
         if (i >= H) break;
         double acc = 0.0;
+#pragma unroll
         for (int l = -f; l <= f; l++) acc += hs[r + l + f][threadIdx.x] * fv.t[l + f];
         dst[blockIdx.z * np + (size_t)i * W + j] = acc;
     }
@@ -1082,8 +1086,16 @@ int filter_hv(papof_handle* h, const double* src, double* dst, double* tmp, int 
         PAPOF_TRY(filter_h(h, src, tmp, H, W, planes, fh));
         return filter_v(h, tmp, dst, H, W, planes, fv);
     }
-    hipLaunchKernelGGL(k_filter_hv, dim3((W + BX - 1) / BX, (H + kHvRows - 1) / kHvRows, planes), dim3(BX, BY), 0, h->stream,
-                       src, dst, H, W, fh, fv);
+    const dim3 grid((W + BX - 1) / BX, (H + kHvRows - 1) / kHvRows, planes), block(BX, BY);
+    const int f = fh.fsize == fv.fsize ? fh.fsize : -1;
+    if (f == 1)
+        hipLaunchKernelGGL(k_filter_hv<1>, grid, block, 0, h->stream, src, dst, H, W, fh, fv);
+    else if (f == 2)
+        hipLaunchKernelGGL(k_filter_hv<2>, grid, block, 0, h->stream, src, dst, H, W, fh, fv);
+    else if (f == 3)
+        hipLaunchKernelGGL(k_filter_hv<3>, grid, block, 0, h->stream, src, dst, H, W, fh, fv);
+    else
+        hipLaunchKernelGGL(k_filter_hv<-1>, grid, block, 0, h->stream, src, dst, H, W, fh, fv);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
