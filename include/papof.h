@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PAPOF_VERSION 101 /* 0.1.1: papof_params gained interpolation / noise_model */
+#define PAPOF_VERSION 102 /* 0.1.2: measurement / test aids (papof_last_sor_stats, papof_strip_plan, papof_test_sor_strips); 0.1.1: papof_params gained interpolation / noise_model */
 
 enum {
     PAPOF_OK = 0,
