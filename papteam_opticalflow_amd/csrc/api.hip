@@ -270,7 +270,9 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
                 double*& va, int H, int W, int fc, double alpha, int n_outer, int n_inner, int n_sor, double omega,
                 int mode, SolveBuffers& B, PhaseClock& clk, const double* im1s_ready = nullptr,
                 bool final_warp = true, unsigned* prog = nullptr, size_t prog_per_solve = 0, double* out_u = nullptr,
-                double* out_v = nullptr) {
+                double* out_v = nullptr, bool fold_warp = false) {
+    // fold_warp: nobody but getDxs' smoothing reads the warped frame 2 (default branches, caller = flow_device): it is
+    // evaluated inside the smoothing kernel from (u, v) and never written -- `warp` is then neither read nor written here
     // prog: cleared progress counters of this level's solves (solve i: prog + i * prog_per_solve), or null;
     // out_u / out_v: where the LAST update writes the flow instead of the other pair of planes (the caller's result buffers)
     const Taps g = smooth5_taps();
@@ -283,7 +285,10 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
     }
     for (int count = 0; count < n_outer; count++) {
         clk.phase(PAPOF_T_PHASE1_GENERATE);
-        PAPOF_TRY(smooth_hv_blend(h, warp, im1s, B.blend, B.imdt, H, W, fc));  // both passes + blend + imdt, fused
+        if (fold_warp)
+            PAPOF_TRY(warp_smooth_blend(h, f1, f2, u, v, im1s, B.blend, B.imdt, H, W, fc));  // warp + both passes + blend + imdt
+        else
+            PAPOF_TRY(smooth_hv_blend(h, warp, im1s, B.blend, B.imdt, H, W, fc));  // both passes + blend + imdt, fused
         // inner fixed-point iterations (src/OpticalFlow.cpp:290-506): after the first one, phi is taken at u + du and
         // psi at imdt + imdx*du + imdy*dv with the increment of the previous solve; the solve itself restarts at 0
         for (int hh = 0; hh < n_inner; hh++) {
@@ -318,7 +323,7 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
         double* const phi_next = count + 1 < n_outer ? B.phi : nullptr;  // the next outer iteration's phi, fused in
         // the re-warp after the LAST outer iteration of a level (:516) is read by nobody when the caller is flow_device (the
         // next level warps anew, the result is the bicubic warp of the originals): final_warp = false skips it
-        const bool rewarp = !B.bgx && (final_warp || count + 1 < n_outer || B.gm);
+        const bool rewarp = !fold_warp && !B.bgx && (final_warp || count + 1 < n_outer || B.gm);
         if (out_u && out_v && count + 1 == n_outer) {  // the level's result goes straight to the caller's buffers
             PAPOF_TRY(update_warp_phi(h, B.sp, u, v, out_u, out_v, f1, f2, warp, phi_next, H, W, fc, rewarp));
             u = out_u;
@@ -880,10 +885,12 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
                                 P.n_inner == 1 && !B.bgx && !B.gm && want >= 2 &&
                                 plan_strips(h, B.sp, lh, n_sor_k, n_outer_k, want, sch);
             LevelInit li{k == levels - 1, nullptr, nullptr, ph, pw, 0.0, 0.0, 1 / ratio};
+            const bool fold_warp = !strips && !B.bgx && !B.gm;  // the warped frame 2 lives only inside the smoothing kernel
             if (k == levels - 1) {  // src/OpticalFlow.cpp:801-806
                 PAPOF_HIP(hipMemsetAsync(u, 0, np * sizeof(double), h->stream));
                 PAPOF_HIP(hipMemsetAsync(v, 0, np * sizeof(double), h->stream));
-                PAPOF_HIP(hipMemcpyAsync(warp, f2, np * fc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+                if (!fold_warp)
+                    PAPOF_HIP(hipMemcpyAsync(warp, f2, np * fc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
                 if (B.bgx) PAPOF_TRY(bicubic_planes(h, f2, lh, lw, fc, B));
             } else {  // :809-816
                 const double xr = (double)lw / pw, yr = (double)lh / ph, inv = 1 / ratio;
@@ -898,7 +905,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
                 }
                 std::swap(u, u2);
                 std::swap(v, v2);
-                if (strips) {
+                if (strips || fold_warp) {
                 } else if (!B.bgx) {
                     PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc));
                 } else {  // interpolation == Bicubic (:816): warpImageBicubicRef, no threshold here
@@ -913,7 +920,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
             else
                 PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, u2, v2, lh, lw, fc, P.alpha, n_outer_k, P.n_inner, n_sor_k,
                                       P.omega, P.sor_mode, B, clk, S1[k], false, prog_k, exact ? LP[k].prog_per : 0, out_u,
-                                      out_v));
+                                      out_v, fold_warp));
             pw = lw;
             ph = lh;
         }

@@ -316,6 +316,8 @@ int smooth_v_blend(papof_handle* h, const double* tmp, const double* im1s, doubl
                    int W, int planes, const Rect* rc = nullptr);
 int smooth_hv_blend(papof_handle* h, const double* warp, const double* im1s, double* blend, double* imdt, int H,
                     int W, int planes, int row0 = 0, int row1 = -1);  // rows row0 .. row1-1 (-1: to the last row)
+int warp_smooth_blend(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v,
+                      const double* im1s, double* blend, double* imdt, int H, int W, int planes);  // warp folded in
 int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlanes* prev, double* phi, int H, int W,
                 const Rect* rc = nullptr);
 int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,

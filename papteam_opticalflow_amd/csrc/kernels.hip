@@ -357,6 +357,64 @@ __global__ __launch_bounds__(256) void k_smooth_hv_blend(const double* __restric
     }
 }
 
+// The same with the WARP folded in (one-GPU default path): the warped frame 2 (OpticalFlow::warpFL, src/OpticalFlow.cpp:
+// 154-159, 516) is read by nobody but this smoothing, so it is never written to HBM -- a block evaluates warp_value() for
+// every cell of its tile grown by the filters' reach (clamped coordinates, i.e. exactly the cells k_smooth_hv_blend would
+// have loaded from the warped plane: same bits), keeps them in LDS, and runs both passes out of LDS.  Saves the plane's
+// round trip (16 B x channels per pixel and iteration) and the warp kernel at the start of every level.
+__device__ __forceinline__ double warp_value(const double* __restrict__ im1, const double* __restrict__ im2, double fx,
+                                             double fy, int i, int j, int H, int W) {  // one plane of warp_pixel()
+    const double y = i + fy;
+    const double x = j + fx;
+    if (x < 0 || x > W - 1 || y < 0 || y > H - 1) return im1[(size_t)i * W + j];
+    return bilinear_apply(im2, bilinear_taps(W, H, x, y));
+}
+constexpr int kWsRows = 16;  // rows per block of the warp-folded smoothing (32 rows: 0.13 ms per 1080p pair slower)
+__global__ __launch_bounds__(256) void k_warp_smooth_blend(const double* __restrict__ im1, const double* __restrict__ im2,
+                                                           const double* __restrict__ u, const double* __restrict__ v,
+                                                           const double* __restrict__ im1s, double* __restrict__ blend,
+                                                           double* __restrict__ imdt, int H, int W, Taps g,
+                                                           unsigned long long* stamp) {
+    // one channel per block (blockIdx.z).  [Also measured: one block looping over the channels with the sampling taps of its
+    // cells kept in registers -- 0.2 ms per 1080p pair SLOWER (register pressure, ten barriers per block).]
+    __shared__ double raw[kWsRows + 4][BX + 4];
+    __shared__ double hs[kWsRows + 4][BX];
+    stamp_now(stamp);
+    const int j0 = blockIdx.x * BX, i0 = blockIdx.y * kWsRows;
+    const size_t np = (size_t)H * W;
+    const double *p1 = im1 + blockIdx.z * np, *p2 = im2 + blockIdx.z * np;
+    for (int c = threadIdx.y * BX + threadIdx.x; c < (kWsRows + 4) * (BX + 4); c += BX * BY) {
+        const int r = c / (BX + 4), cc = c - r * (BX + 4);
+        const int i = clampi(i0 + r - 2, H), j = clampi(j0 + cc - 2, W);
+        const size_t o = (size_t)i * W + j;
+        raw[r][cc] = warp_value(p1, p2, u[o], v[o], i, j, H, W);
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < kWsRows + 4; r += BY) {
+        double acc = 0.0;
+#pragma unroll
+        for (int l = -2; l <= 2; l++) acc += raw[r][threadIdx.x + 2 + l] * g.t[l + 2];
+        hs[r][threadIdx.x] = acc;
+    }
+    __syncthreads();
+    const int j = j0 + threadIdx.x;
+    if (j >= W) return;
+    for (int r = threadIdx.y; r < kWsRows; r += BY) {
+        const int i = i0 + r;
+        if (i >= H) break;
+        const size_t o = blockIdx.z * np + (size_t)i * W + j;
+        double s2 = 0.0;
+#pragma unroll
+        for (int l = -2; l <= 2; l++) s2 += hs[r + l + 2][threadIdx.x] * g.t[l + 2];
+        const double s1 = im1s[o];
+        double t = s1;
+        t *= 0.4;
+        t += s2 * 0.6;
+        blend[o] = t;
+        imdt[o] = s2 - s1;
+    }
+}
+
 // index (in doubles) of cell (i, j) in an SOR operand plane.  Skew mode: paired planes, (phi,xy) (a1,a2) (b1,b2)
 // (du,dv) interleaved, cell (i, j) at (i + j + qt) * hp + (i + rt) -- see common.h.
 struct SkewIdx {
@@ -1164,6 +1222,14 @@ int smooth_hv_blend(papof_handle* h, const double* warp, const double* im1s, dou
     hipLaunchKernelGGL(k_smooth_hv_blend, dim3((W + BX - 1) / BX, (row1 - row0 + kFuseRows - 1) / kFuseRows, planes),
                        dim3(BX, BY), 0, h->stream, warp, im1s, blend, imdt, H, W, smooth5_taps(), take_stamp(h), row0,
                        row1);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+int warp_smooth_blend(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v,
+                      const double* im1s, double* blend, double* imdt, int H, int W, int planes) {
+    hipLaunchKernelGGL(k_warp_smooth_blend, dim3((W + BX - 1) / BX, (H + kWsRows - 1) / kWsRows, planes), dim3(BX, BY), 0,
+                       h->stream, im1, im2, u, v, im1s, blend, imdt, H, W, smooth5_taps(), take_stamp(h));
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
