@@ -1921,7 +1921,10 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             const int pairs = (n_sor + 1) / 2;
             A.xcd_affine = (h->sor_xcd_affine && (sd.nb <= 8 || h->sor_xcd_affine > 1)) ? 1 : 0;
             const int per_q = A.xcd_affine ? 8 * ((sd.nb + 7) / 8) : sd.nb;  // workgroups per pair of sweeps
-            const int Rf = h->sor_depth > 0 ? h->sor_depth : 6;
+            // depth 8: isolated solves are equal at 6 / 8 / 10 (profiles/r01_s3_sor_sweeps.txt), but INSIDE a pair -- other
+            // cache contents, the preparation stream beside it -- 8 is 0.18 ms per 1080p pair faster than 6 and 0.07 faster
+            // than 10 (same-box A/B, profiles/r02_ab_variants.txt)
+            const int Rf = h->sor_depth > 0 ? h->sor_depth : 8;
             const int chunk = std::max(1, resident_tasks(h) / per_q);
             for (int q0 = 0; q0 < pairs; q0 += chunk) {
                 A.k0 = q0;
@@ -1950,7 +1953,8 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         // also what a hand-off costs.  Measured (profiles/r01_s2_sor_depth_sweep.txt): the big levels want the deeper
         // pipeline (throughput; with the mid-iteration poll 1440x810: 0.85 -> 0.81 ms, 1080x607: 0.68 -> 0.65 ms), the
         // small, hand-off-bound levels the shorter one (607x341: 0.53 -> 0.47 ms).
-        const int R = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 8 ? 8 : 6);
+        const int R = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 8 ? 8 : 6);  // (in-pair A/B of round 2: 6 / 10 on the big
+                                                                                // levels, 4 / 8 on the small ones: all worse)
         const int chunk = std::max(1, resident_tasks(h) / per_k);
         for (int k0 = 0; k0 < n_sor; k0 += chunk) {
             A.k0 = k0;
@@ -2129,7 +2133,7 @@ int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double a
     A.stamp = nullptr;
     if (h->sor_mark) h->sor_mark(h->sor_mark_ctx, 1);
     if (sd.fuse == 2) {
-        const int pairs = (n_sor + 1) / 2, Rf = h->sor_depth > 0 ? h->sor_depth : 6;
+        const int pairs = (n_sor + 1) / 2, Rf = h->sor_depth > 0 ? h->sor_depth : 8;
         const dim3 grid(nbl * pairs);
         if (Rf <= 6)
             hipLaunchKernelGGL((k_sor_fused<6, true>), grid, dim3(kLanes), 0, h->stream, A);
