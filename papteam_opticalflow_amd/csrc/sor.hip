@@ -2192,7 +2192,7 @@ int sor_group_size(const papof_handle* h, int H, int W, int n_sor) {
 static int sor_fuse_size(const papof_handle* h, int H, int W, int n_sor, int group) {
     if (!h || !h->use_dpp || n_sor < 2 || group > 1) return 1;
     if (h->sor_fuse > 0) return h->sor_fuse == 2 ? 2 : 1;
-    return skew_dims(H, W, n_sor).nb >= 16 ? 2 : 1;
+    return skew_dims(H, W, n_sor).nb >= 16 ? 2 : 1;  // (inside a pair, round 2: from 14 / 10 bands on: 0.15 / 0.47 ms slower)
 }
 
 int sor_bind(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor) {
