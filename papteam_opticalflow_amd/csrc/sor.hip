@@ -81,6 +81,9 @@ namespace {
 #ifndef PAPOF_V_FDM6
 #define PAPOF_V_FDM6 3
 #endif
+#ifndef PAPOF_V_FDM8
+#define PAPOF_V_FDM8 4  // ... at depth 8, the default since round 2 (in-pair A/B: 4 is 0.05 ms per 1080p pair faster than 5, 6 slower)
+#endif
 #ifndef PAPOF_V_MIDPOLL
 #define PAPOF_V_MIDPOLL 8
 #endif
@@ -723,7 +726,7 @@ __device__ __forceinline__ void f_run(const ExactArgs& A, const Task& T, const L
     Unroll<R, R - 1, DPP>::fill_unknowns(T, L, c);
     pl = poll(D);
     // markers, polls and the peeled first iteration: exactly as in k_sor_exact (see there)
-    constexpr int H = R / 2, DM = R == 6 ? PAPOF_V_FDM6 : (R >= 6 ? R - 3 : H);
+    constexpr int H = R / 2, DM = R == 6 ? PAPOF_V_FDM6 : (R == 8 ? PAPOF_V_FDM8 : (R >= 6 ? R - 3 : H));
     constexpr int CA = H + DM - R, CB = DM;
     static_assert(CA >= 0 && CA < H && CB >= H && CB < R, "marker consumption points");
     unsigned ma = 0u, mb = 0u;
