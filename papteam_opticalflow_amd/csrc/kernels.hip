@@ -88,7 +88,10 @@ __global__ void k_filter_v(const double* __restrict__ src, double* __restrict__ 
 // are those of k_filter_h followed by k_filter_v -- the v pass reads the h-filtered values of the rows clamp(i + l), here
 // rows of the block's LDS image -- so the bits are the same, but the h-filtered plane never goes to HBM (2.4 instead of
 // 4 plane transfers at half-width 3).  A block owns kHvRows rows x 64 columns of one plane.
-constexpr int kHvRows = 32, kHvMaxF = 4;
+#ifndef PAPOF_V_HVROWS
+#define PAPOF_V_HVROWS 64  // in-pair A/B (round 2): 16 / 32 / 64 / 96 / 128 rows: 10.99 / 10.98 / 10.92 / 10.91 / 10.94 ms per 1080p pair
+#endif
+constexpr int kHvRows = PAPOF_V_HVROWS, kHvMaxF = 4;
 template <int F>  // F = the half-width of both passes as a compile-time constant (fully unrolled tap loops), or -1: run time
 __global__ __launch_bounds__(256) void k_filter_hv(const double* __restrict__ src, double* __restrict__ dst, int H, int W,
                                                    Taps fh, Taps fv) {
@@ -204,7 +207,10 @@ __global__ void k_im2feature(const double* __restrict__ im, double* __restrict__
 // The same through an LDS tile of gray values (one-GPU path): a block owns kFeatRows rows x 64 columns, evaluates gray
 // ONCE per cell of the tile grown by the 5-tap filters' reach (same expression: same bits) and takes the two derivative
 // sums out of LDS in the same order -- 4 instead of 27 cached loads per pixel.
-constexpr int kFeatRows = 16;
+#ifndef PAPOF_V_FEATROWS
+#define PAPOF_V_FEATROWS 16
+#endif
+constexpr int kFeatRows = PAPOF_V_FEATROWS;
 template <int C>
 __global__ __launch_bounds__(256) void k_im2feature_tiled(const double* __restrict__ im, double* __restrict__ feat, int H,
                                                           int W, Taps d) {
@@ -369,7 +375,10 @@ __device__ __forceinline__ double warp_value(const double* __restrict__ im1, con
     if (x < 0 || x > W - 1 || y < 0 || y > H - 1) return im1[(size_t)i * W + j];
     return bilinear_apply(im2, bilinear_taps(W, H, x, y));
 }
-constexpr int kWsRows = 16;  // rows per block of the warp-folded smoothing (32 rows: 0.13 ms per 1080p pair slower)
+#ifndef PAPOF_V_WSROWS
+#define PAPOF_V_WSROWS 16
+#endif
+constexpr int kWsRows = PAPOF_V_WSROWS;  // rows per block of the warp-folded smoothing (32 rows: 0.13 ms per 1080p pair slower)
 __global__ __launch_bounds__(256) void k_warp_smooth_blend(const double* __restrict__ im1, const double* __restrict__ im2,
                                                            const double* __restrict__ u, const double* __restrict__ v,
                                                            const double* __restrict__ im1s, double* __restrict__ blend,
