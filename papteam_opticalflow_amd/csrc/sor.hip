@@ -84,6 +84,12 @@ namespace {
 #ifndef PAPOF_V_FDM8
 #define PAPOF_V_FDM8 4  // ... at depth 8, the default since round 2 (in-pair A/B: 4 is 0.05 ms per 1080p pair faster than 5, 6 slower)
 #endif
+#ifndef PAPOF_V_FMIDPOLL
+#define PAPOF_V_FMIDPOLL 10  // fused kernel: depth from which the progress poll is issued in mid-iteration
+#endif
+#ifndef PAPOF_V_FSELECTIVE
+#define PAPOF_V_FSELECTIVE false  // fused kernel: poll only the counter that is still missing while waiting
+#endif
 #ifndef PAPOF_V_MIDPOLL
 #define PAPOF_V_MIDPOLL 8
 #endif
@@ -716,7 +722,7 @@ __device__ __forceinline__ void f_run(const ExactArgs& A, const Task& T, const L
     Slots<R> c;
     Unroll<R, R - 1, DPP>::fill_coef(T, L, c);
     Polls pl = poll(D);
-    if (!wait_covered<1, 64>(A, pl, D, R)) end_task();  // staged start-up, see k_sor_exact
+    if (!wait_covered<1, 64, PAPOF_V_FSELECTIVE>(A, pl, D, R)) end_task();  // staged start-up, see k_sor_exact
     {  // centre of the first cells = the right operand of "step -1" (lanes >= 2: left of column 0, zero)
         const unsigned first = (F.own_block || L.pd == kOob) ? kOob : L.pd - L.pos_d;
         const D2 c0 = as_d2(__builtin_amdgcn_raw_buffer_load_b128(T.rd, first, 0, kAuxSc1));
@@ -732,8 +738,8 @@ __device__ __forceinline__ void f_run(const ExactArgs& A, const Task& T, const L
     unsigned ma = 0u, mb = 0u;
     const auto iteration = [&](int i, auto first_c) {
         constexpr bool first = decltype(first_c)::value;
-        if (!wait_covered<1, 64>(A, pl, D, (i + 2) * R)) end_task();
-        constexpr bool kMidPoll = R >= 10;
+        if (!wait_covered<1, 64, PAPOF_V_FSELECTIVE>(A, pl, D, (i + 2) * R)) end_task();
+        constexpr bool kMidPoll = R >= PAPOF_V_FMIDPOLL;
         Polls pn{0u, 0u, 0u};
         if (!kMidPoll) pn = poll(D);
         FSeg<R, 0, CA, DPP, first, ID2>::run(A, T, L, F, i * R, c, S1, S2);
