@@ -275,6 +275,14 @@ struct State {
 // compiler cannot fold away).  Otherwise the slot's registers stay live across the refill, the refill lands in other
 // registers, and the loop-carried slots need register copies at the top of every iteration -- which the compiler
 // guards with `s_waitcnt vmcnt(0)`: a full drain of the software pipeline once per iteration.
+// A 16-byte store reads its data registers over more than one cycle: a VALU write of those registers needs two wait
+// states behind the store (gfx940+), and the compiler's hazard recognizer provides them for its OWN instructions only -- not
+// for the inline-asm moves of moved() below, which it may schedule (and register-allocate) straight behind a store.  Found
+// in round 2: with a second wave on the SIMD the store can slip a cycle, and the move then overwrites data not yet read
+// (wrong quads of lanes, only under concurrency -- DESIGN.md §5.1).  Every store of the solver steps is therefore followed
+// by store_data_guard(): two wait states, whatever comes next.
+__device__ __forceinline__ void store_data_guard() { asm volatile("s_nop 1" ::: "memory"); }
+
 __device__ __forceinline__ double moved(double x) {
     double y;
     asm volatile("v_mov_b64 %0, %1" : "=v"(y) : "v"(x));
@@ -310,6 +318,7 @@ __device__ __forceinline__ void step(const ExactArgs& A, const Task& T, const La
     s2 += xy * duN;
     const double dvN = om1 * S.dvC + pb.y * (pc.y - s2);
     __builtin_amdgcn_raw_buffer_store_b128(as_u4(duN, dvN), T.rd, L.st, (unsigned)s * L.pos_d, kAuxSc1);
+    store_data_guard();
     S.duL = duN;
     S.dvL = dvN;
     S.phiL = moved(phiC);
@@ -628,10 +637,10 @@ __device__ __forceinline__ void f_step(const ExactArgs& A, const Task& T, const 
     } else {
         // ID2 -- the identity second sweep of the LAST pair of an odd sweep count -- is the same arithmetic with (a1, a2)
         // masked to zero and 1 - omega -> 1 (F.om1b, set by the kernel): the exact pass-through the ghost lanes use.  (A
-        // shortcut that simply forwarded the first sweep's results two steps later, without the arithmetic, returned wrong
-        // cells -- a quad of lanes here and there -- whenever OTHER kernels ran on the chip at the same time: three handles
-        // in flight, or a solve cut into strips; never alone.  Same source semantics, so a code-generation hazard of that
-        // variant; not pursued further, the variant is gone.  tests/test_gpu_parity.py keeps the reproducer.)
+        // shortcut that simply forwarded the first sweep's results two steps later returned wrong quads of lanes whenever
+        // OTHER kernels ran on the chip at the same time: in its loop the compiler had placed the inline-asm moves of
+        // moved() straight behind the 16-byte stores, into the stores' data registers -- the hazard store_data_guard() now
+        // closes for every variant.  The shortcut saved nothing that matters and stays out.)
         const D2 qa = as_d2(c.pa[t2]), qc = as_d2(c.pc[t2]);
         const u32x4 qbm = ID2 ? (c.pb[t2] & u32x4{0u, 0u, 0u, 0u}) : c.pb[t2];
         const D2 qb = as_d2(qbm);
@@ -683,6 +692,7 @@ __device__ __forceinline__ void f_step(const ExactArgs& A, const Task& T, const 
     const double dvN = F.om1a * S1.dvC + pb.y * (pc.y - s2);
     const double o1 = F.first_out ? duN : duN2, o2 = F.first_out ? dvN : dvN2;
     __builtin_amdgcn_raw_buffer_store_b128(as_u4(o1, o2), T.rd, L.st, (unsigned)s * L.pos_d, kAuxSc1);
+    store_data_guard();
     S2.duL = duN2;
     S2.dvL = dvN2;
     S2.duC = duR2;
@@ -946,6 +956,7 @@ __device__ __forceinline__ void g_step(const GroupArgs& A, const Task& T, const 
     else
         __builtin_amdgcn_raw_buffer_store_b128(out, T.rd, L.st, (unsigned)s * L.pos_d, kAuxSc1);
     __builtin_amdgcn_raw_buffer_store_b128(out, T.rd, L.hs + (unsigned)s * 16u, 0, kAuxSc1);  // lane 62 -> halo row
+    store_data_guard();
     S.duL = duN;
     S.dvL = dvN;
     S.phiL = moved(phiC);  // see moved(): no slot register may stay live across its refill
