@@ -48,4 +48,43 @@ for path in sys.argv[1:]:
     for k, v in hits.items():
         print("  ", k[:90], len(v), "e.g. wait states", v[0][0], "|", v[0][1][:60], "|", v[0][2][:50])
 
+
+# second pass: a DPP instruction reading a VGPR that an INLINE-ASM move wrote fewer than 2 wait states earlier (the hazard
+# recognizer looks for VALU writers; an inline-asm statement is not one to it)
+def any_regs(tok):
+    return regs(tok.strip().rstrip(","))
+for path in sys.argv[1:]:
+    ins, in_asm = [], False
+    for ln in open(path).read().split("\n"):
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+            continue
+        ins.append((t.split(";")[0].strip(), in_asm))
+    dpp_hits = 0
+    for i, (t, a) in enumerate(ins):
+        if not a or not t.startswith("v_"):
+            continue
+        dst = any_regs(t.split()[1])
+        ws = 0
+        for j in range(i + 1, min(i + 4, len(ins))):
+            t2 = ins[j][0]
+            if ws >= 2:
+                break
+            if "dpp" in t2:
+                srcs = set()
+                for tok in t2.split()[2:]:
+                    srcs |= any_regs(tok)
+                if srcs & dst:
+                    dpp_hits += 1
+            m2 = re.match(r"s_nop\s+(\d+)", t2)
+            ws += (int(m2.group(1)) + 1) if m2 else 1
+    print(path, "DPP reads of an inline-asm result within < 2 wait states:", dpp_hits)
+    globals()["total"] = globals().get("total", 0) + dpp_hits
+
 sys.exit(1 if globals().get('total', 0) else 0)
