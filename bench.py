@@ -322,8 +322,15 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     sor_sec = 0.0
+    solve_log = {}  # (h, w, n_sor, kind, depth) -> [solves, launches, seconds] over the timed steps (roofline.by_level)
     for _ in range(args.steps):
         sor_sec += one_step()[6]
+        if gpu is not None and args.pairs == 1:  # a host-side read of what the call already recorded: no device work
+            for e in gpu.last_sor_solves():
+                acc = solve_log.setdefault((e["h"], e["w"], e["n_sor"], e["kind"], e["depth"]), [0, 0, 0.0])
+                acc[0] += 1
+                acc[1] += e["launches"]
+                acc[2] += e["sec"]
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -360,6 +367,27 @@ def main():
                 traffic = json.load(open(tpath)).get("%s_%s_%s" % (args.res, args.schedule, args.mode))
             except Exception:
                 traffic = None
+        # per level and per kernel: the solver kernels' own HIP-event time of every solve, as the library recorded it
+        KIND = {0: "k_sor_exact", 1: "k_sor_fused", 2: "k_sor_group", 3: "k_sor_blocked<redblack>",
+                4: "k_sor_blocked<jacobi>", 5: "k_sor_redblack/k_sor_jacobi (one launch per half-sweep)"}
+        by_level, by_kernel = [], {}
+        for (lh, lw, ns, kind, depth), (n_solves, n_launch, sec) in sorted(solve_log.items(), key=lambda kv: -kv[0][0] * kv[0][1]):
+            if sec <= 0 or n_launch <= 0:
+                continue
+            gbytes = lh * lw * ns * BYTES_PER_UPDATE * n_solves / 1e9
+            name = "%s<%d>" % (KIND.get(kind, "?"), depth) if kind in (0, 1, 2) else KIND.get(kind, "?")
+            by_level.append({"level": "%dx%d" % (lw, lh), "sweeps": ns, "kernel": name, "solves": n_solves,
+                             "launches": n_launch, "avg_launch_us": round(sec / n_launch * 1e6, 1),
+                             "avg_solve_us": round(sec / n_solves * 1e6, 1),
+                             "achieved": round(gbytes / sec, 1), "frac": round(gbytes / sec / HBM_PEAK_GBS, 4)})
+            k = by_kernel.setdefault(name, {"launches": 0, "sec": 0.0, "gbytes": 0.0})
+            k["launches"] += n_launch
+            k["sec"] += sec
+            k["gbytes"] += gbytes
+        by_kernel = {n: {"launches": v["launches"], "avg_launch_us": round(v["sec"] / v["launches"] * 1e6, 1),
+                         "share_of_sor_time": round(v["sec"] / max(sor_sec, 1e-30), 4),
+                         "achieved": round(v["gbytes"] / v["sec"], 1), "frac": round(v["gbytes"] / v["sec"] / HBM_PEAK_GBS, 4)}
+                     for n, v in by_kernel.items()}
         # parity statistic of the metric: max-abs delta (u, v) against the untouched reference's golden values
         parity = None
         try:
@@ -384,9 +412,11 @@ def main():
             "config": {"workload": "%dx%d frame pair, %d-level pyramid, schedule %s (outer %d+%dk, SOR %d+%dk), "
                                    "%s-order SOR" % (w, h, args.levels, args.schedule, sched[0], sched[1], sched[2],
                                                      sched[3], args.mode),
-                       "value_is": "device-resident: both frames and the results already / still in HBM "
-                                   "(papof_flow_device, timers: total + SOR kernels); the drop-in call with host buffers "
-                                   "and all ten timers is value_call_inclusive",
+                       "value_is": "device-resident, as the bench contract prescribes (inputs already resident in HBM when "
+                                   "the timed region starts; papof_flow_device, timers: total + SOR kernels).  "
+                                   "BASELINE.md's caller-side definition -- H*W over the wall time of ONE "
+                                   "coarse2fine_flow(im1, im2, levels) call with float64 numpy frames in and out, both "
+                                   "PCIe transfers and all ten timers -- is value_call_inclusive on this same line",
                        "pairs_in_flight_per_gpu": args.pairs,
                        "parallelism": "replicas: one independent frame pair per GPU" if world > 1 else "1 GPU"},
             "max_abs_duv_vs_reference": parity,
@@ -395,6 +425,13 @@ def main():
                              args.mode, "/".join(str(d) for d in depths), "half-sweeps" if mode == 1 else "sweeps"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": ("profiles/pmc_traffic.json (STATIC: HBM bytes per launch from this round's "
+                                            "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH_SIZE "
+                                            "doubled per the guide's gfx950 correction; not measured in this run)")
+                         if traffic is not None else None,
+                         "frac_on_traffic": round(traffic * launches / 1e9 / sor_step / HBM_PEAK_GBS, 4)
+                         if traffic and sor_step > 0 and launches else None,
+                         "by_level": by_level or None, "by_kernel": by_kernel or None,
                          "launches_per_step": launches, "cell_updates_per_step": updates,
                          "avg_launch_ms": round(sor_step * 1e3 / launches, 4) if launches else None,
                          "sor_ms_per_step": round(sor_step * 1e3, 4)},

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PAPOF_VERSION 102 /* 0.1.2: measurement / test aids (papof_last_sor_stats, papof_strip_plan, papof_test_sor_strips); 0.1.1: papof_params gained interpolation / noise_model */
+#define PAPOF_VERSION 103 /* 0.1.3: papof_last_sor_solves, exact-order band split over ranks (papof_tiles_*, PAPOF_SOR_EXACT); 0.1.2: measurement / test aids (papof_last_sor_stats, papof_strip_plan, papof_test_sor_strips); 0.1.1: papof_params gained interpolation / noise_model */
 
 enum {
     PAPOF_OK = 0,
@@ -315,6 +315,13 @@ int papof_sor_plan(papof_handle* h, int height, int width, int n_sor, int sor_mo
  * solver kernels in all (a level solved as strips of bands issues one launch per strip and solve), and how many
  * seconds of the reported Phase5_SOR are launches on the strip streams, i.e. ran beside the main stream's time line. */
 int papof_last_sor_stats(papof_handle* h, int* launches, double* strip_streams_sec);
+
+/* Measurement aid for bench.py (roofline.by_level / by_kernel): the solves of the LAST papof_flow* / papof_seq_push* call on
+ * this handle, in stream order.  *n = their number; for i < min(*n, cap): info[6 i ..] = {height, width, sweeps, kind,
+ * depth, launches} with kind 0 = k_sor_exact, 1 = k_sor_fused, 2 = k_sor_group, 3 / 4 = k_sor_blocked red-black / Jacobi,
+ * 5 = one launch per (half-)sweep; depth = software-pipeline depth R (exact order) or (half-)sweeps per launch (blocked);
+ * sec[i] = the solver kernels' own HIP-event seconds of that solve (0 when the call collected no timers). */
+int papof_last_sor_solves(papof_handle* h, int cap, int* n, int* info, double* sec);
 
 /* Test aid: the strip schedule (api.hip: smooth_flow_strips) a level of height x width with `n_sor` sweeps and
  * `n_outer` outer iterations gets on this handle.  *strips = S (1: the level is not cut).  out, if not NULL, receives

@@ -50,6 +50,7 @@ SYMBOLS = [
     "papof_flow_dequantize16", "papof_flow_to_bgr", "papof_set_graph_mode", "papof_sor_plan", "papof_last_sor_stats", "papof_strip_plan", "papof_test_sor_strips",
     "papof_pyramid_levels_for_min_width", "papof_stage_smoothflow_ex", "papof_stage_est_gaussian_mixture",
     "papof_stage_bicubic_warp_ex", "papof_tiles_comm_info", "papof_host_alloc", "papof_host_free",
+    "papof_last_sor_solves",
 ]
 
 
@@ -137,6 +138,8 @@ def load():
     L.papof_host_free.argtypes = [c_void_p]
     L.papof_sor_plan.argtypes = [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     L.papof_last_sor_stats.argtypes = [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]
+    L.papof_last_sor_solves.argtypes = [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                        ctypes.POINTER(ctypes.c_double)]
     L.papof_test_sor_strips.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                         ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(c_int)]
     L.papof_strip_plan.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int),
@@ -146,27 +149,46 @@ def load():
     return L
 
 
-# ---- result arrays in page-locked memory, recycled when the caller drops them (include/papof.h: papof_host_alloc) ----
-_pinned_pool = {}       # nbytes -> [address, ...] ready for reuse
-_pinned_live = [0]      # bytes currently owned by callers
+# ---- result arrays in page-locked memory, recycled when the caller drops them (include/papof.h: papof_host_alloc).
+# The accounting (size classes, a budget that counts idle AND live blocks, LRU eviction, atexit drain) is pinned_pool.py.
+# NOTE for callers that fork(): the ROCm runtime maps page-locked host memory so that a forked CHILD does not inherit it
+# (arrays returned by coarse2fine_flow would be unmapped in multiprocessing workers started by fork after the call).
+# Copy the results (np.array(vx)) before forking, use the spawn start method, or set PAPOF_PINNED_OUT=0.
+from . import pinned_pool as _pinned_pool_mod
+
+_pool = None
+
+
+def _pinned_alloc(nbytes):
+    p = c_void_p()
+    if load().papof_host_alloc(ctypes.c_size_t(nbytes), ctypes.byref(p)) != 0 or not p.value:
+        return 0
+    return p.value
+
+
+def _pinned_free(addr):
+    load().papof_host_free(c_void_p(addr))
+
+
+def pinned_pool():
+    """the process-wide pool of page-locked result blocks (created on first use)"""
+    global _pool
+    if _pool is None:
+        _pool = _pinned_pool_mod.PinnedPool(_pinned_alloc, _pinned_free)
+    return _pool
 
 
 class _PinnedBlock(object):
-    """Owns one pinned allocation; returns it to the pool when the numpy array built on it is garbage-collected."""
-    __slots__ = ("addr", "nbytes", "__weakref__")
+    """Owns one pinned block; returns it to the pool when the numpy array built on it is garbage-collected."""
+    __slots__ = ("addr", "cls", "__weakref__")
 
-    def __init__(self, addr, nbytes):
-        self.addr, self.nbytes = addr, nbytes
+    def __init__(self, addr, cls):
+        self.addr, self.cls = addr, cls
 
     def __del__(self):
         try:
-            _pinned_live[0] -= self.nbytes
-            lst = _pinned_pool.setdefault(self.nbytes, [])
-            if len(lst) < 6:
-                lst.append(self.addr)
-            else:
-                load().papof_host_free(c_void_p(self.addr))
-        except Exception:  # interpreter shutdown
+            pinned_pool().give_back(self.addr, self.cls)
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
             pass
 
 
@@ -174,19 +196,14 @@ def result_array(shape):
     """float64 array for (vx, vy, warpI2): pinned and recycled (PAPOF_PINNED_OUT=0: plain np.zeros).  Every element is
     overwritten by the call it is handed to, as the reference overwrites its np.zeros arrays."""
     nbytes = 8 * int(np.prod(shape))
-    if os.environ.get("PAPOF_PINNED_OUT", "1") == "0" or nbytes < (1 << 20) or _pinned_live[0] + nbytes > (1 << 30):
+    if os.environ.get("PAPOF_PINNED_OUT", "1") == "0" or nbytes < (1 << 20):
         return np.zeros(shape)
-    lst = _pinned_pool.get(nbytes)
-    if lst:
-        addr = lst.pop()
-    else:
-        p = c_void_p()
-        if load().papof_host_alloc(ctypes.c_size_t(nbytes), ctypes.byref(p)) != 0 or not p.value:
-            return np.zeros(shape)
-        addr = p.value
+    got = pinned_pool().take(nbytes)
+    if got is None:  # budget exhausted (PAPOF_PINNED_BUDGET_MB, default 1024) or the allocator failed
+        return np.zeros(shape)
+    addr, cls = got
     buf = (ctypes.c_char * nbytes).from_address(addr)
-    buf._papof_block = _PinnedBlock(addr, nbytes)  # the array keeps `buf` alive, `buf` keeps the block alive
-    _pinned_live[0] += nbytes
+    buf._papof_block = _PinnedBlock(addr, cls)  # the array keeps `buf` alive, `buf` keeps the block alive
     return np.frombuffer(buf, dtype=np.float64).reshape(shape)
 
 
@@ -541,6 +558,19 @@ class Papof:
         nl, sec = c_int(0), c_double(0)
         _chk(self.L.papof_last_sor_stats(self.h, ctypes.byref(nl), ctypes.byref(sec)), "papof_last_sor_stats")
         return nl.value, sec.value
+
+    def last_sor_solves(self):
+        """[dict(h, w, n_sor, kind, depth, launches, sec)] for every solve of the last flow call, in stream order
+        (include/papof.h: papof_last_sor_solves)"""
+        n = c_int(0)
+        _chk(self.L.papof_last_sor_solves(self.h, 0, ctypes.byref(n), None, None), "papof_last_sor_solves")
+        cap = n.value
+        if cap == 0:
+            return []
+        info, sec = (c_int * (6 * cap))(), (ctypes.c_double * cap)()
+        _chk(self.L.papof_last_sor_solves(self.h, cap, ctypes.byref(n), info, sec), "papof_last_sor_solves")
+        keys = ("h", "w", "n_sor", "kind", "depth", "launches")
+        return [dict(zip(keys, info[6 * i:6 * i + 6]), sec=sec[i]) for i in range(min(cap, n.value))]
 
     def test_sor_strips(self, h, w, n_sor, split_band, reps=3, delay_us=0):
         """(mismatching cells of a solve cut into two strips vs the whole solve, bands of the layout)"""

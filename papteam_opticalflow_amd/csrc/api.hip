@@ -607,6 +607,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         key.vy = d_vy;
         key.warp = d_warp;
         key.arena_base = A.base;
+        key.sync_base = h->sync_words;
         for (GraphEntry& e : h->graphs)
             if (std::memcmp(&e.key, &key, sizeof key) == 0) ge = &e;
         if (!ge) {
@@ -676,10 +677,12 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     uclk.only_sor = true;
     h->strip_events_used = 0;
     h->sor_launches = 0;
+    h->sor_log.clear();
     h->sor_upper_sec = 0.0;
     clk.stamps = true;  // the main stream's phase boundaries are in-kernel stamps, not events (flow_internal.h)
     h->stamps_used = 0;
     h->next_stamp = nullptr;
+    h->stamp_stream = h->stream;  // only launches on the main stream take phase stamps (take_stamp)
 
     total.phase(PAPOF_T_TOTAL);
     for (int i = 0; i < levels; i++) {  // the two pyramid slots: always the first allocations, at fixed offsets
@@ -969,6 +972,8 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     clk.collect(tm);
     pclk.collect(tm);
     total.collect(tm);
+    if (clk.sor_span_sec.size() == h->sor_log.size())  // one span per solve (not when a level ran as strips)
+        for (size_t i = 0; i < h->sor_log.size(); i++) h->sor_log[i].sec = clk.sor_span_sec[i];
     if (uclk.err != PAPOF_OK) return PAPOF_EDEVICE;
     {   // Phase5_SOR = the solver kernels' own time, all strips (on the main chain's time line only the lowest strip's)
         double tu[PAPOF_N_TIMERS];
@@ -1930,6 +1935,25 @@ int papof_last_sor_stats(papof_handle* h, int* launches, double* strip_streams_s
     if (!h) return PAPOF_EINVAL;
     if (launches) *launches = h->sor_launches;
     if (strip_streams_sec) *strip_streams_sec = h->sor_upper_sec;
+    return PAPOF_OK;
+}
+
+int papof_last_sor_solves(papof_handle* h, int cap, int* n, int* info, double* sec) {
+    if (!h || !n) return PAPOF_EINVAL;
+    *n = (int)h->sor_log.size();
+    for (int i = 0; i < *n && i < cap; i++) {
+        const papof_handle::SorSolveLog& e = h->sor_log[i];
+        if (info) {
+            int* o = info + (size_t)i * 6;
+            o[0] = e.H;
+            o[1] = e.W;
+            o[2] = e.n_sor;
+            o[3] = e.kind;
+            o[4] = e.depth;
+            o[5] = e.launches;
+        }
+        if (sec) sec[i] = e.sec;
+    }
     return PAPOF_OK;
 }
 

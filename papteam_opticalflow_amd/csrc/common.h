@@ -211,6 +211,8 @@ struct GraphKey {
     const void *fa, *fb;
     void *vx, *vy, *warp;
     const void* arena_base;
+    const void* sync_base;  // the progress counters / abort word (h->sync_words): captured memset nodes and kernel arguments hold
+                            // their addresses, and a later call that needs more counters reallocates them
 };
 struct GraphEntry {
     GraphKey key;
@@ -258,6 +260,14 @@ struct papof_handle {
     int sor_resident = 0;            // tasks per launch of the exact-order kernels; 0 = 8 per CU (sor.hip: resident_tasks)
     unsigned* sor_prog_next = nullptr;  // cleared progress counters for the NEXT sor_solve() (else it clears its own)
     int sor_launches = 0;            // exact-order solver kernels launched by the current / last call (measurement: bench.py)
+    // one entry per sor_solve() of the current / last call, in stream order (measurement: bench.py's roofline.by_level);
+    // kind: 0 k_sor_exact, 1 k_sor_fused, 2 k_sor_group, 3 k_sor_blocked red-black, 4 k_sor_blocked Jacobi, 5 naive kernels;
+    // sec: the solver kernels' own HIP-event time (filled when the call's timers are collected, else 0)
+    struct SorSolveLog {
+        int H, W, n_sor, kind, depth, launches;
+        double sec;
+    };
+    std::vector<SorSolveLog> sor_log;
     double sor_upper_sec = 0.0;      // ... of which: event time of the launches on the strip streams (added to Phase5_SOR)
     // strips (api.hip: smooth_flow_strips): a level's plane as S horizontal strips of solver bands, each on its own
     // stream, so that a strip's non-solver kernels run in the shadow of the other strips' solves
@@ -275,6 +285,8 @@ struct papof_handle {
     unsigned long long* stamps = nullptr;      // pinned host copy, fetched once per call
     int stamps_cap = 0, stamps_used = 0, stamps_fetched = 0;
     unsigned long long* next_stamp = nullptr;  // taken (and cleared) by the next kernel launch that supports stamps
+    hipStream_t stamp_stream = nullptr;        // ... on THIS stream only (the main chain): a launch on a strip / preparation
+                                               // stream must not consume a stamp of the main stream's phase clock
     bool phase_events = true;        // PAPOF_PHASE_EVENTS=0: record only the total and the solver kernels' events (A/B of the events' cost)
     int sor_xcd_affine = 1;          // 0: off; 1: when there are at most 8 bands; 2: always (see sor.hip)      // all sweeps of a band on one XCD (block index -> task mapping, speed only)
     // sequence mode (papof_seq_*): the pyramid of the last pushed frame stays in the arena and becomes "frame 1" of
@@ -290,6 +302,7 @@ struct papof_handle {
 namespace papof {
 
 inline unsigned long long* take_stamp(papof_handle* h) {
+    if (h->stamp_stream && h->stream != h->stamp_stream) return nullptr;
     unsigned long long* s = h->next_stamp;
     h->next_stamp = nullptr;
     return s;

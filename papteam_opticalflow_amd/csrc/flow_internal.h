@@ -30,6 +30,7 @@ struct PhaseClock {
     bool only_sor = false;  // measurement aid (PAPOF_PHASE_EVENTS=0): nothing but Phase5_SOR (and the total) is measured
     bool stamps = false;
     std::vector<std::pair<int, int>> marks;  // stamp mode: (slot, timer index) in stream order
+    std::vector<double> sor_span_sec;        // collect(): seconds of every Phase5_SOR span, in stream order (one per solve)
     size_t new_event() {
         if (h->events_used == h->events.size()) {
             hipEvent_t e;
@@ -81,6 +82,7 @@ struct PhaseClock {
             float ms = 0;
             if (hipEventElapsedTime(&ms, h->events[s.second.first], h->events[s.second.second]) == hipSuccess)
                 t[s.first] += ms * 1e-3;
+            if (s.first == PAPOF_T_PHASE5_SOR) sor_span_sec.push_back(ms * 1e-3);
         }
         // h->stamps holds the slots 0 .. stamps_fetched-1 (copied back by fetch_stamps() before the stream was drained)
         for (size_t i = 0; i + 1 < marks.size(); i++) {

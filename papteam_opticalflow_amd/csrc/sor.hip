@@ -276,11 +276,13 @@ struct State {
 // registers, and the loop-carried slots need register copies at the top of every iteration -- which the compiler
 // guards with `s_waitcnt vmcnt(0)`: a full drain of the software pipeline once per iteration.
 // A 16-byte store reads its data registers over more than one cycle: a VALU write of those registers needs two wait
-// states behind the store (gfx940+), and the compiler's hazard recognizer provides them for its OWN instructions only -- not
-// for the inline-asm moves of moved() below, which it may schedule (and register-allocate) straight behind a store.  Found
-// in round 2: with a second wave on the SIMD the store can slip a cycle, and the move then overwrites data not yet read
-// (wrong quads of lanes, only under concurrency -- DESIGN.md §5.1).  Every store of the solver steps is therefore followed
-// by store_data_guard(): two wait states, whatever comes next.
+// states behind the store (gfx940+).  Nothing provides them here: the compiler's hazard recognizer does not look inside
+// inline-asm statements (the moves of moved() below, which it may schedule and register-allocate straight behind a
+// store), and it skips this hazard ALTOGETHER for buffer stores whose soffset is a register -- the form of every solver
+// store -- so compiler-generated VALU writes are unguarded at these stores as well.  Found in round 2: with a second wave on
+// the SIMD the store can slip a cycle, and the write then overwrites data not yet read (wrong quads of lanes, only under
+// concurrency -- DESIGN.md 5.1).  Every store of the solver steps is therefore followed by store_data_guard(): two wait
+// states, whatever comes next; tools/scan_store_hazard.py checks the generated code of every build (csrc/Makefile).
 __device__ __forceinline__ void store_data_guard() { asm volatile("s_nop 1" ::: "memory"); }
 
 __device__ __forceinline__ double moved(double x) {
@@ -1811,6 +1813,9 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
     const auto mark = [&](int on) {
         if (h->sor_mark) h->sor_mark(h->sor_mark_ctx, on);
     };
+    const auto log_solve = [&](int kind, int depth, int launches) {
+        h->sor_log.push_back(papof_handle::SorSolveLog{H, W, n_sor, kind, depth, launches, 0.0});
+    };
     if (mode == PAPOF_SOR_EXACT) {
         if (!sp.skew) return PAPOF_EINVAL;
         const SkewDims sd = skew_dims(H, W, n_sor, sp.sd.group, sp.sd.fuse);
@@ -1935,6 +1940,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             }
             PAPOF_HIP(hipGetLastError());
             mark(0);
+            log_solve(2, Rg, (groups + chunk - 1) / chunk);
             return PAPOF_OK;
         }
         if (sd.fuse == 2) {  // two sweeps per wave (k_sor_fused); effective pipeline depth R - 2
@@ -1962,6 +1968,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             }
             PAPOF_HIP(hipGetLastError());
             mark(0);
+            log_solve(1, Rf, (pairs + chunk - 1) / chunk);
             return PAPOF_OK;
         }
         // measured: with at most one band per XCD the affinity is worth 3-4 % (small pyramid levels); beyond that the
@@ -1996,6 +2003,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         }
         PAPOF_HIP(hipGetLastError());
         mark(0);
+        log_solve(0, R, (n_sor + chunk - 1) / chunk);
         return PAPOF_OK;
     }
     if (sp.skew) return PAPOF_EINVAL;
@@ -2003,6 +2011,10 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         mark(1);
         PAPOF_TRY(sor_blocked_solve(h, sp, H, W, alpha, omega, mode, mode == PAPOF_SOR_REDBLACK ? 2 * n_sor : n_sor));
         mark(0);
+        {
+            const BlockedPlan bp = blocked_plan(h, mode, H, W, mode == PAPOF_SOR_REDBLACK ? 2 * n_sor : n_sor);
+            log_solve(mode == PAPOF_SOR_REDBLACK ? 3 : 4, bp.q * (bp.base + (bp.rem ? 1 : 0)), bp.n_launch);
+        }
         return PAPOF_OK;
     }
     // PAPOF_RB_NAIVE=1: one launch per half-sweep straight on the planes (the first implementation; kept as a cross-check)
@@ -2015,6 +2027,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             for (int colour = 0; colour < 2; colour++)
                 PAPOF_TRY(sor_redblack_halfsweep(h, sp, H, W, alpha, omega, colour, Rect{0, 0, W, H}));
         mark(0);
+        log_solve(5, 1, 2 * n_sor);
         return PAPOF_OK;
     }
     if (mode == PAPOF_SOR_JACOBI) {
@@ -2037,6 +2050,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             PAPOF_HIP(hipMemcpyAsync(sp.dv, rv, np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         }
         mark(0);
+        log_solve(5, 1, n_sor);
         return PAPOF_OK;
     }
     return PAPOF_EINVAL;

@@ -46,54 +46,85 @@ cdef extern from "papof.h":
 # ---- result arrays in page-locked memory, recycled when the caller drops them (include/papof.h: papof_host_alloc).
 # The reference allocates vx, vy, warpI2 with np.zeros for every call (Code/Serial/pyflow.pyx:44-52); every element is
 # overwritten by the call, so recycled memory gives the same arrays -- without 83 MB of first-touch page faults, a staged
-# copy and an munmap per 1080p pair.  PAPOF_PINNED_OUT=0 (or more than 1 GiB of such arrays alive) falls back to np.zeros.
+# copy and an munmap per 1080p pair.  The pool is BOUNDED (papteam_opticalflow_amd/pinned_pool.py: the budget counts idle
+# and live blocks, PAPOF_PINNED_BUDGET_MB, default 1024; size classes; LRU eviction; drained at exit); beyond it, or with
+# PAPOF_PINNED_OUT=0, the arrays are plain np.zeros as in the reference.
+# fork(): page-locked host memory is not inherited by a forked child (ROCm maps it that way) -- a caller that forks
+# workers AFTER a call and reads the returned arrays in the child must copy them first (np.array(vx)), use the spawn
+# start method, or set PAPOF_PINNED_OUT=0.
 import os as _os
 from cpython.ref cimport Py_INCREF
 from libc.stdint cimport uintptr_t
 
-_pool = {}        # nbytes -> [pointer, ...] ready for reuse
-_live_bytes = 0   # bytes of pinned result arrays currently owned by callers
 _PINNED = _os.environ.get("PAPOF_PINNED_OUT", "1") != "0"
 
 
+def _load_pool_module():
+    import importlib.util
+    path = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), _os.pardir, "pinned_pool.py")
+    spec = importlib.util.spec_from_file_location("_papof_pinned_pool", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _host_alloc(nbytes):
+    cdef void* p = NULL
+    if papof_host_alloc(<size_t> nbytes, &p) != 0 or p == NULL:
+        return 0
+    return <uintptr_t> p
+
+
+def _host_free(addr):
+    papof_host_free(<void*> <uintptr_t> addr)
+
+
+_pool = None
+
+
+def _pinned_pool():
+    """the process-wide PinnedPool of this module (None: pinned_pool.py not found -> plain np.zeros results)"""
+    global _pool, _PINNED
+    if _pool is None and _PINNED:
+        try:
+            _pool = _load_pool_module().PinnedPool(_host_alloc, _host_free)
+        except Exception:
+            _PINNED = False
+    return _pool
+
+
 cdef class _PinnedBlock:
-    cdef void* ptr
-    cdef size_t nbytes
+    cdef uintptr_t addr
+    cdef size_t cls
 
     def __dealloc__(self):
-        global _live_bytes
-        if self.ptr != NULL:
-            _live_bytes -= self.nbytes
-            lst = _pool.setdefault(self.nbytes, [])
-            if len(lst) < 6:
-                lst.append(<uintptr_t> self.ptr)
-            else:
-                papof_host_free(self.ptr)
-            self.ptr = NULL
+        if self.addr != 0:
+            try:
+                if _pool is not None:
+                    _pool.give_back(self.addr, self.cls)
+            except Exception:  # interpreter shutdown
+                pass
+            self.addr = 0
 
 
 cdef object _result_array(tuple shape):
-    global _live_bytes
     cdef size_t nbytes = 8
     for d in shape:
         nbytes *= <size_t> d
-    if not _PINNED or nbytes < (1 << 20) or _live_bytes + nbytes > (1 << 30):
+    if not _PINNED or nbytes < (1 << 20):
         return np.zeros(shape, dtype=np.float64)
-    cdef void* p = NULL
-    lst = _pool.get(nbytes)
-    if lst:
-        p = <void*> <uintptr_t> lst.pop()
-    elif papof_host_alloc(nbytes, &p) != 0 or p == NULL:
+    pool = _pinned_pool()
+    got = pool.take(nbytes) if pool is not None else None
+    if got is None:
         return np.zeros(shape, dtype=np.float64)
     cdef _PinnedBlock blk = _PinnedBlock.__new__(_PinnedBlock)
-    blk.ptr = p
-    blk.nbytes = nbytes
-    _live_bytes += nbytes
+    blk.addr = <uintptr_t> got[0]
+    blk.cls = <size_t> got[1]
     cdef np.npy_intp dims[3]
     cdef int nd = len(shape)
     for i in range(nd):
         dims[i] = shape[i]
-    arr = np.PyArray_SimpleNewFromData(nd, dims, np.NPY_FLOAT64, p)
+    arr = np.PyArray_SimpleNewFromData(nd, dims, np.NPY_FLOAT64, <void*> blk.addr)
     Py_INCREF(blk)
     np.PyArray_SetBaseObject(arr, blk)
     return arr

@@ -24,3 +24,27 @@ def test_no_store_data_hazard_in_generated_code(tmp_path, unit, extra):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scan_store_hazard.py"), asm], capture_output=True, text=True)
     print(out.stdout)
     assert out.returncode == 0, out.stdout
+
+
+def _scan_text(tmp_path, body):
+    p = tmp_path / "t.s"
+    p.write_text("k_test:\n" + body)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scan_store_hazard.py"), str(p)], capture_output=True, text=True)
+    return out.returncode, out.stdout
+
+
+@pytest.mark.parametrize("name,body,bad", [
+    ("store-data WAR, inline-asm writer", "buffer_store_dwordx4 v[4:7], v1, s[0:3], s9 offen\n;;#ASMSTART\nv_mov_b64 v[4:5], v[8:9]\n;;#ASMEND\n", True),
+    ("store-data WAR, compiler writer", "buffer_store_dwordx4 v[4:7], v1, s[0:3], s9 offen\nv_add_f64 v[6:7], v[8:9], v[10:11]\n", True),
+    ("store-data WAR, guarded", "buffer_store_dwordx4 v[4:7], v1, s[0:3], s9 offen\ns_nop 1\n;;#ASMSTART\nv_mov_b64 v[4:5], v[8:9]\n;;#ASMEND\n", False),
+    ("asm write -> DPP read", ";;#ASMSTART\nv_mov_b64 v[4:5], v[8:9]\n;;#ASMEND\nv_mov_b32_dpp v6, v4 wave_shr:1 row_mask:0xf bank_mask:0xf\n", True),
+    ("asm write -> DPP read, 2 apart", ";;#ASMSTART\nv_mov_b64 v[4:5], v[8:9]\n;;#ASMEND\nv_add_f64 v[20:21], v[22:23], v[24:25]\nv_mul_f64 v[30:31], v[22:23], v[24:25]\nv_mov_b32_dpp v6, v4 wave_shr:1 row_mask:0xf bank_mask:0xf\n", False),
+    ("asm write -> readfirstlane", ";;#ASMSTART\nv_mov_b32 v4, v8\n;;#ASMEND\nv_readfirstlane_b32 s5, v4\n", True),
+    ("VALU writes SGPR -> asm VMEM", "v_readfirstlane_b32 s9, v4\ns_nop 1\n;;#ASMSTART\nbuffer_load_dword v7, v1, s[0:3], s9 offen\n;;#ASMEND\n", True),
+    ("VALU writes SGPR -> asm VMEM, 5 apart", "v_readfirstlane_b32 s9, v4\ns_nop 4\n;;#ASMSTART\nbuffer_load_dword v7, v1, s[0:3], s9 offen\n;;#ASMEND\n", False),
+    ("trans -> non-trans", ";;#ASMSTART\nv_rcp_f32 v4, v8\n;;#ASMEND\nv_mul_f32 v5, v4, v9\n", True),
+    ("compiler pair (recognizer's job, not reported)", "v_mov_b32 v4, v8\nv_mov_b32_dpp v6, v4 wave_shr:1 row_mask:0xf bank_mask:0xf\n", False),
+])
+def test_scanner_knows_the_hazard_kinds(tmp_path, name, body, bad):
+    rc, out = _scan_text(tmp_path, body)
+    assert (rc != 0) == bad, (name, out)

@@ -95,6 +95,31 @@ def test_tiled_config4_schedule_full_hd_tile_grid(gpu):
     assert n_ex == 15 * (5 + 1) + 4 + 2  # per solve: 60 half-sweeps / 10 - 1 exchanges + (u, v); level changes; gather
 
 
+def test_config5_1920x1080_2x4_tiles_at_size(gpu, oracle):
+    """BASELINE.json configs[4] AT ITS SIZE, as far as one GPU allows: the 1920x1080 pair, 5 levels, config-4 schedule
+    (3 outer / 30 SOR), sharded as 2 x 4 tiles with ghost zones 10 half-sweeps deep -- the eight ranks are threads of this
+    process on one device (LOCAL transport: device copies where the multi-GPU run has RCCL sends; orchestration, regions,
+    message plans and the ghost-zone schedule are the same code).  Must be bit-identical to the one-GPU red-black call AND
+    to the oracle run in the same mode (~7 s of one host core), with the exchange count DESIGN.md 7 states: per solve
+    60 / 10 - 1 = 5 (du, dv) exchanges + 1 of (u, v) = 6, x 15 solves, + 4 level changes + 2 for the final gather = 96."""
+    a, b = cases.load_pair("1920")
+    kw = dict(n_outer=3, n_outer_per_level=0, n_sor=30, n_sor_per_level=0)
+    P = _params(**kw)
+    (vx, vy, wi, t), (n_ex, n_bytes) = _run_tiles(8, 2, 4, 10, a, b, 5, P)
+    want = gpu.coarse2fine_flow(a, b, 5, P)[:3]
+    for name, g, w in zip(("vx", "vy", "warpI2"), (vx, vy, wi), want):
+        assert np.array_equal(g, w), "%s differs from the one-GPU red-black call: max-abs %.3e" % (name, np.abs(g - w).max())
+    assert n_ex == 15 * (5 + 1) + 4 + 2 == 96
+    p = oracle.default_params()
+    for k, v in dict(kw, sor_mode=1).items():
+        setattr(p, k, v)
+    ow = oracle.coarse2fine_flow(a, b, 5, p)[:3]
+    for name, g, w in zip(("vx", "vy", "warpI2"), (vx, vy, wi), ow):
+        assert np.array_equal(g, w), "%s differs from the same-mode oracle: max-abs %.3e" % (name, np.abs(g - w).max())
+    print("config 5 at size: 2x4 tiles of 480x540, %d exchanges, %.1f MB moved by rank 0, %.1f ms on one device" %
+          (n_ex, n_bytes / 1e6, t[9] * 1e3))
+
+
 def test_tiled_rejects_exact_order_and_inner_iterations(gpu):
     from papteam_opticalflow_amd import PapofError
     a, b = cases.load_pair("240")
