@@ -535,6 +535,14 @@ int smooth_flow_strips(papof_handle* h, const StripSchedule& q, const LevelInit&
 
 int feature_channels(int C) { return C == 3 ? 5 : (C == 1 ? 3 : C); }
 
+void ensure_strip_streams(papof_handle* h) {  // without them levels are simply not cut
+    while (h->strip_streams.size() < 3) {
+        hipStream_t ss = nullptr;
+        if (hipStreamCreateWithFlags(&ss, hipStreamNonBlocking) != hipSuccess) break;
+        h->strip_streams.push_back(ss);
+    }
+}
+
 // An interleaved HWC frame resident on the device: fp64 in [0,1] (the reference's buffers) or the decoded uint8
 // samples, which are scaled by 1/255 while they are planarised (OpticalFlowCalculation.py:69-70).
 struct FrameIn {
@@ -1097,12 +1105,10 @@ int papof_create(int device, papof_handle** out) {
         papof_destroy(h);
         return PAPOF_ENODEVICE;
     }
-    for (int i = 0; i < 3; i++) {  // strip streams (smooth_flow_strips); without them levels are simply not cut
-        hipStream_t ss = nullptr;
-        if (hipStreamCreateWithFlags(&ss, hipStreamNonBlocking) != hipSuccess) break;
-        h->strip_streams.push_back(ss);
-    }
     if (const char* cs = std::getenv("PAPOF_STRIPS")) h->strips = std::max(0, std::atoi(cs));
+    // strip streams (smooth_flow_strips; opt-in) are created only where they are used: a handle is two streams otherwise, and
+    // the runtime multiplexes streams onto a limited number of hardware queues (eight tile ranks on one device = 16 streams)
+    if (h->strips > 1) ensure_strip_streams(h);
     if (const char* cs = std::getenv("PAPOF_GRAPH")) h->use_graph = std::atoi(cs) != 0;
     if (const char* cs = std::getenv("PAPOF_OVERLAP")) h->overlap_prep = std::atoi(cs) != 0;
     if (const char* cs = std::getenv("PAPOF_PHASE_EVENTS")) h->phase_events = std::atoi(cs) != 0;
@@ -1994,7 +2000,9 @@ int papof_strip_plan(papof_handle* h, int height, int width, int n_sor, int n_ou
 // (sor_solve_bands), `reps` times; *mismatches = 16-byte cells of the (du, dv) planes, both parities, that differ.
 int papof_test_sor_strips(papof_handle* h, int height, int width, int n_sor, int split_band, int reps, int delay_us,
                           long long* mismatches, int* bands) {
-    if (!h || !mismatches || h->strip_streams.empty()) return PAPOF_EINVAL;
+    if (!h || !mismatches) return PAPOF_EINVAL;
+    ensure_strip_streams(h);
+    if (h->strip_streams.empty()) return PAPOF_EINVAL;
     const size_t np = (size_t)height * width;
     Scope S(h, img_bytes(height, width, 1, 16) + sor_scratch_bytes(height, width, n_sor) +
                    12 * (size_t)height * width * sizeof(double));

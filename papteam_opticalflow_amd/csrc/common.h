@@ -374,8 +374,15 @@ int sor_check(papof_handle* h);  // after a stream sync: PAPOF_ETIMEOUT if a dev
 // counters of all `n_solves` solves of a level (before the streams fork); launch bands b0 .. b1-1 of solve `solve_idx`
 bool sor_strips_supported(const papof_handle* h, const SorPlanes& sp, int n_sor);
 int sor_strips_begin(papof_handle* h, const SorPlanes& sp, int n_sor, int n_solves);
+// `split`: the ranges of bands of one solve live in different handles (tiles.hip: bands_flow; sor.hip: ExactArgs)
+struct SorSplit {
+    double* peer_du;      // (du, dv) planes of the handle that runs band b1 (same bound layout), null: none
+    unsigned* peer_prog;  // its counters of this solve
+    bool top_cut, bot_cut;
+};
 int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor,
-                    unsigned* prog, int b0, int b1);
+                    unsigned* prog, int b0, int b1, const SorSplit* split = nullptr);
+int sor_bind_plain(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor);  // as sor_bind, one sweep per wave / workgroup
 // progress counters cleared ahead of the solves that use them (flow_device: all of a call's, on the preparation stream)
 size_t sor_counters_words(int H, int W, int n_sor);
 int sor_counters_ensure(papof_handle* h, size_t words);

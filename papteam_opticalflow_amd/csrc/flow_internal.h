@@ -119,5 +119,6 @@ int pyramid_plan(int H, int W, double ratio, int nlev, std::vector<Level>& L, st
 int build_pyramid(papof_handle* h, const std::vector<Level>& L, const std::vector<PyrPlan>& plan, int C, bool second,
                   double* tmp_a, double* tmp_b);
 int feature_channels(int C);
+void ensure_strip_streams(papof_handle* h);
 
 }  // namespace papof

@@ -113,6 +113,18 @@ struct ExactArgs {
     double nalpha, om1;
     unsigned long long* dbg;  // diagnostics (PAPOF_SOR_DBG): per task 8 time stamps (s_memrealtime, 100 MHz), else null
     unsigned long long* stamp;  // phase stamp (flow_internal.h: PhaseClock): block 0 writes the 100 MHz clock on entry
+    // SPLIT launches (one solve cut into ranges of bands that live in DIFFERENT handles / address spaces, tiles.hip:
+    // bands_flow).  Every rank keeps the full-size banded (du, dv) planes and counters of the global layout and runs the bands
+    // b0 .. b0 + nbl - 1.  The one edge that crosses a cut -- ghost lane 0 of band b0 reads, per step, the new value of the
+    // row above, which is lane 62 of band b0 - 1 on the rank above -- goes through an INBOX inside the reader's own planes:
+    // the slot of block b0 - 1 (never computed locally), cell k >> 1 of parity k & 1 -- one cell per sweep, so nothing is
+    // ever reused within a solve and no write-after-read edge crosses the cut (n_sor <= 128).  The rank above stores that
+    // cell into the reader's planes (peer_du) beside its own store, with the same position arithmetic, and publishes its
+    // progress into the reader's counters (peer_prog) beside its own.
+    double* peer_du;      // (du, dv) planes of the rank that runs band b0 + nbl (same layout), or null
+    unsigned* peer_prog;  // its progress counters of this solve
+    int top_cut;          // band b0 has its upper neighbour on another rank: read the inbox cell
+    int bot_cut;          // band b0 + nbl - 1 has its lower neighbour on another rank: also write that rank's inbox / counter
 };
 
 __device__ __forceinline__ void stamp_now(unsigned long long* s) {
@@ -229,6 +241,7 @@ struct Slots {
 struct Task {  // wave-uniform task constants (SGPRs)
     __amdgpu_buffer_rsrc_t ra, rb, rc, rd;  // descriptors of the four paired planes
     __amdgpu_buffer_rsrc_t rp;              // the progress counters (k_sor_exact / k_sor_fused)
+    __amdgpu_buffer_rsrc_t rd2, rp2;        // SPLIT launches: (du, dv) planes and counters of the rank below the cut
 };
 
 // Publication of a task's progress WITHOUT a branch: every lane executes the store, the per-lane offset is out of
@@ -248,6 +261,7 @@ struct LaneOffs {
     unsigned st;     // (du, dv) store of step s: own block, this parity, cell lane (ghosts store their pass-through)
     unsigned pos_c;  // bytes per coefficient skew position = hp * 16
     unsigned pos_d;  // bytes per (du, dv) position = nb * 1 KiB
+    unsigned hs;     // SPLIT: store of step s into the inbox of the rank below (lane 62 of the band above a cut; else off)
 };
 
 template <int R, int t>
@@ -291,7 +305,7 @@ __device__ __forceinline__ double moved(double x) {
     return y;
 }
 
-template <int R, int t, bool DPP>
+template <int R, int t, bool DPP, bool SPLIT = false>
 __device__ __forceinline__ void step(const ExactArgs& A, const Task& T, const LaneOffs& L, double om1, int s,
                                      Slots<R>& c, State& S) {
     const double nalpha = A.nalpha;
@@ -320,6 +334,8 @@ __device__ __forceinline__ void step(const ExactArgs& A, const Task& T, const La
     s2 += xy * duN;
     const double dvN = om1 * S.dvC + pb.y * (pc.y - s2);
     __builtin_amdgcn_raw_buffer_store_b128(as_u4(duN, dvN), T.rd, L.st, (unsigned)s * L.pos_d, kAuxSc1);
+    if (SPLIT)  // lane 62 of the band above a cut: the same cell into the inbox of the rank below (every other lane: off)
+        __builtin_amdgcn_raw_buffer_store_b128(as_u4(duN, dvN), T.rd2, L.hs, (unsigned)s * L.pos_d, kAuxSc1);
     store_data_guard();
     S.duL = duN;
     S.dvL = dvN;
@@ -335,7 +351,7 @@ struct Unroll {
     static __device__ __forceinline__ void run(const ExactArgs& A, const Task& T, const LaneOffs& L, double om1,
                                                int s0, Slots<R>& c, State& S) {
         Unroll<R, t - 1, DPP>::run(A, T, L, om1, s0, c, S);
-        step<R, t, DPP>(A, T, L, om1, s0 + t, c, S);
+        step<R, t, DPP, false>(A, T, L, om1, s0 + t, c, S);
     }
     static __device__ __forceinline__ void fill_coef(const Task& T, const LaneOffs& L, Slots<R>& c) {
         Unroll<R, t - 1, DPP>::fill_coef(T, L, c);
@@ -355,16 +371,16 @@ struct Unroll<R, -1, DPP> {
 };
 
 // steps t0 .. t1-1 of the unrolled iteration
-template <int R, int t0, int t1, bool DPP>
+template <int R, int t0, int t1, bool DPP, bool SPLIT = false>
 struct Seg {
     static __device__ __forceinline__ void run(const ExactArgs& A, const Task& T, const LaneOffs& L, double om1,
                                                int s0, Slots<R>& c, State& S) {
-        step<R, t0, DPP>(A, T, L, om1, s0 + t0, c, S);
-        Seg<R, t0 + 1, t1, DPP>::run(A, T, L, om1, s0, c, S);
+        step<R, t0, DPP, SPLIT>(A, T, L, om1, s0 + t0, c, S);
+        Seg<R, t0 + 1, t1, DPP, SPLIT>::run(A, T, L, om1, s0, c, S);
     }
 };
-template <int R, int t1, bool DPP>
-struct Seg<R, t1, t1, DPP> {
+template <int R, int t1, bool DPP, bool SPLIT>
+struct Seg<R, t1, t1, DPP, SPLIT> {
     static __device__ __forceinline__ void run(const ExactArgs&, const Task&, const LaneOffs&, double, int, Slots<R>&,
                                                State&) {}
 };
@@ -438,7 +454,7 @@ __device__ __forceinline__ bool wait_covered(const ExactArgs& A, const Polls& pl
     return true;
 }
 
-template <int R, bool DPP>
+template <int R, bool DPP, bool SPLIT = false>
 __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     static_assert(R >= 4 && R % 2 == 0, "two markers per iteration");
     stamp_now(A.stamp);
@@ -493,7 +509,12 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     L.st = mine + L.pos_d + (unsigned)b * kBlock + lane * 16u;
     // lanes >= 1: own block, cell lane - 1; lane 0: the row above, NEW value: block b-1, cell 62, written by (b-1, k) 63
     // steps ahead of ours.  (Selects, not branches: a divergent branch anywhere makes the compiler structurise the kernel.)
-    const unsigned pd_above = b > 0 ? mine + 64u * L.pos_d + (unsigned)(b - 1) * kBlock + 62u * 16u : kOob;
+    // (SPLIT, first band below a cut: the inbox cell of this sweep -- see ExactArgs -- instead of cell 62)
+    const bool cut_top = SPLIT && A.top_cut && b == A.b0, cut_bot = SPLIT && A.bot_cut && b == A.b0 + A.nbl - 1;
+    const unsigned up_cell = cut_top ? (unsigned)(k >> 1) : 62u;
+    const unsigned pd_above = b > 0 ? mine + 64u * L.pos_d + (unsigned)(b - 1) * kBlock + up_cell * 16u : kOob;
+    L.hs = (cut_bot && lane == kLanes - 2) ? mine + L.pos_d + (unsigned)b * kBlock + (unsigned)(k >> 1) * 16u : kOob;
+    T.rd2 = __builtin_amdgcn_make_buffer_rsrc((void*)((SPLIT && A.peer_du) ? A.peer_du : A.du), 0, 2u * par_bytes, 0x00020000);
     // Sweep 0 reads du = dv = 0 (src/OpticalFlow.cpp:452-453) as out-of-range offsets, not from memory: the planes need
     // no clearing between solves except for the tail positions no task writes (sor_solve clears them anyway: cache warming).
     L.pd = lane == 0 ? pd_above : (k > 0 ? prev + L.pos_d + (unsigned)b * kBlock + (lane - 1u) * 16u : kOob);
@@ -503,14 +524,21 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     // line would serialise at the memory side
     const unsigned prog_bytes = (unsigned)A.n_sor * (unsigned)A.nb * kProgStride * 4u;
     T.rp = __builtin_amdgcn_make_buffer_rsrc((void*)A.prog, 0, prog_bytes, 0x00020000);
+    T.rp2 = __builtin_amdgcn_make_buffer_rsrc((void*)((SPLIT && A.peer_prog) ? A.peer_prog : A.prog), 0, prog_bytes, 0x00020000);
     const unsigned my_prog = lane == 0 ? (unsigned)(k * A.nb + b) * kProgStride * 4u : kOob;
+    const unsigned my_prog2 = cut_bot ? my_prog : kOob;  // the same counter in the memory of the rank below the cut
     Deps D;
     D.has_own = k > 0;
     D.has_up = b > 0;
-    D.has_dn2 = k > 1 && b + 1 < A.nb;
+    // (above a cut the band below reads its own per-sweep inbox cells, never this block: no write-after-read edge)
+    D.has_dn2 = k > 1 && b + 1 < A.nb && !cut_bot;
     D.own = A.prog + ((size_t)(k - 1) * A.nb + b) * kProgStride;
     D.up = A.prog + ((size_t)k * A.nb + (b - 1)) * kProgStride;
     D.dn2 = A.prog + ((size_t)(k - 2) * A.nb + (b + 1)) * kProgStride;
+    const auto publish_all = [&](unsigned steps) {
+        publish(T, my_prog, steps);
+        if (SPLIT) __builtin_amdgcn_raw_buffer_store_b32(steps, T.rp2, my_prog2, 0, 16 /* sc1 */);
+    };
 
     const int n_iter = (ns + R - 1) / R;  // steps beyond ns only touch padding (npos leaves room for them)
     State S;
@@ -561,22 +589,22 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
         // Markers are consumed DM = R - 3 steps after they were issued -- i.e. in the NEXT iteration: consuming a marker
         // waits (in-order vmcnt) for every load issued before it, and with DM = 3 that exposed ~0.35 us of latency twice
         // per iteration (the refills issued in those 3 steps).  R - 3 steps later all of them have long arrived.
-        Seg<R, 0, CA, DPP>::run(A, T, L, om1, i * R, c, S);
+        Seg<R, 0, CA, DPP, SPLIT>::run(A, T, L, om1, i * R, c, S);
         if (!first) {  // marker A of the previous iteration: its steps < (i-1)R + H are complete
             asm volatile("" ::"v"(ma), "v"(S.duL), "v"(S.dvL) : "memory");
             if (uni(ma) != 0u) end_task();
-            publish(T, my_prog, (unsigned)min(ns, (i - 1) * R + H));
+            publish_all((unsigned)min(ns, (i - 1) * R + H));
         }
-        Seg<R, CA, H, DPP>::run(A, T, L, om1, i * R, c, S);
+        Seg<R, CA, H, DPP, SPLIT>::run(A, T, L, om1, i * R, c, S);
         ma = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // marker A: after step H - 1
         if (kMidPoll) pn = poll(D);
-        Seg<R, H, CB, DPP>::run(A, T, L, om1, i * R, c, S);
+        Seg<R, H, CB, DPP, SPLIT>::run(A, T, L, om1, i * R, c, S);
         if (!first) {  // marker B of the previous iteration: steps < i R are complete
             asm volatile("" ::"v"(mb), "v"(S.duL), "v"(S.dvL) : "memory");
             if (uni(mb) != 0u) end_task();
-            publish(T, my_prog, (unsigned)min(ns, i * R));
+            publish_all((unsigned)min(ns, i * R));
         }
-        Seg<R, CB, R, DPP>::run(A, T, L, om1, i * R, c, S);
+        Seg<R, CB, R, DPP, SPLIT>::run(A, T, L, om1, i * R, c, S);
         mb = __hip_atomic_load(A.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // marker B: after step R - 1
         pl = pn;
     };
@@ -588,7 +616,7 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
     }
     // final publication: every store of this wave has left the CU before the counter moves (guide G16/R1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    publish(T, my_prog, (unsigned)ns);
+    publish_all((unsigned)ns);
     if (dbg) dbg[6] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -1872,6 +1900,9 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.k0 = 0;
         A.b0 = 0;
         A.nbl = sd.nb;
+        A.peer_du = nullptr;
+        A.peer_prog = nullptr;
+        A.top_cut = A.bot_cut = 0;
         A.dbg = h->sor_dbg;
         // Fault injection for the tests (tests/test_gpu_parity.py): raise the abort word before the launch, as a task whose
         // bounded wait expired would -- every task must then END (s_endpgm on the fast path, the polling loops' abort
@@ -2118,8 +2149,10 @@ int sor_strips_begin(papof_handle* h, const SorPlanes& sp, int n_sor, int n_solv
 }
 
 int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor,
-                    unsigned* prog, int b0, int b1) {
+                    unsigned* prog, int b0, int b1, const SorSplit* split) {
     if (!sp.skew || n_sor <= 0) return PAPOF_EINVAL;
+    // split over handles (tiles.hip: bands_flow): the plain kernel only, one inbox cell per sweep (ExactArgs)
+    if (split && (sp.sd.fuse != 1 || sp.sd.group != 1 || n_sor > 128 || !h->use_dpp)) return PAPOF_EINVAL;
     const SkewDims sd = skew_dims(H, W, n_sor, sp.sd.group, sp.sd.fuse);
     if (sd.fuse != sp.sd.fuse || sd.hp != sp.sd.hp || sd.npos != sp.sd.npos || sd.qt != sp.sd.qt || sd.nb != sp.sd.nb ||
         sd.n_sor != sp.sd.n_sor || sd.n > sp.cap_cells || sd.nd + sd.nh > sp.cap_cells_d || sd.group > 1)
@@ -2165,8 +2198,20 @@ int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double a
     A.xcd_affine = 0;
     A.dbg = nullptr;
     A.stamp = nullptr;
+    A.peer_du = split ? split->peer_du : nullptr;
+    A.peer_prog = split ? split->peer_prog : nullptr;
+    A.top_cut = split && split->top_cut ? 1 : 0;
+    A.bot_cut = split && split->bot_cut && split->peer_du && split->peer_prog ? 1 : 0;
+    if (split && split->bot_cut && !A.bot_cut) return PAPOF_EINVAL;
     if (h->sor_mark) h->sor_mark(h->sor_mark_ctx, 1);
-    if (sd.fuse == 2) {
+    if (split) {
+        const int R = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 8 ? 8 : 6);
+        const dim3 grid(nbl * n_sor);
+        if (R <= 6)
+            hipLaunchKernelGGL((k_sor_exact<6, true, true>), grid, dim3(kLanes), 0, h->stream, A);
+        else
+            hipLaunchKernelGGL((k_sor_exact<8, true, true>), grid, dim3(kLanes), 0, h->stream, A);
+    } else if (sd.fuse == 2) {
         const int pairs = (n_sor + 1) / 2, Rf = h->sor_depth > 0 ? h->sor_depth : 8;
         const dim3 grid(nbl * pairs);
         if (Rf <= 6)
@@ -2233,6 +2278,15 @@ int sor_bind(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor) {
     if (!sp.skew) return PAPOF_OK;
     const int group = sor_group_size(h, H, W, n_sor);
     const SkewDims sd = skew_dims(H, W, n_sor, group, sor_fuse_size(h, H, W, n_sor, group));
+    if (sd.n > sp.cap_cells || sd.nd + sd.nh > sp.cap_cells_d) return PAPOF_ENOMEM;
+    sp.sd = sd;
+    return PAPOF_OK;
+}
+
+int sor_bind_plain(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor) {
+    (void)h;
+    if (!sp.skew) return PAPOF_EINVAL;
+    const SkewDims sd = skew_dims(H, W, n_sor, 1, 1);
     if (sd.n > sp.cap_cells || sd.nd + sd.nh > sp.cap_cells_d) return PAPOF_ENOMEM;
     sp.sd = sd;
     return PAPOF_OK;

@@ -98,6 +98,23 @@ struct Transport {
     // Everything enqueued on h->stream before the call is visible to the sends; everything enqueued after it sees the
     // received data.
     virtual int exchange(papof_handle* h, const std::vector<Msg>& sends, const std::vector<Msg>& recvs) = 0;
+    // The exact-order band split (bands_flow) lets a solver kernel of one rank write into the planes and counters of the
+    // rank below it: it needs the peers' memory DIRECTLY ADDRESSABLE.  bases(): collective; every rank contributes the base
+    // of its arena and of its counter block and receives everybody's, as pointers valid on ITS device.  barrier(): when it
+    // returns, everything every rank enqueued before its call has completed.
+    virtual int bases(papof_handle*, void*, void*, std::vector<void*>&, std::vector<void*>&) {
+        set_last_error_text("this transport cannot address peer memory from a kernel: the exact-order band split runs on the "
+                            "LOCAL transport (one process, one device) -- see DESIGN.md 7 for the multi-GPU transport it needs");
+        return PAPOF_EINVAL;
+    }
+    virtual int barrier(papof_handle*) { return PAPOF_EINVAL; }
+    // Host-side launch order of the ranks' solver kernels of one solve (bands_flow): rank r's tasks spin on counters that
+    // the rank above publishes, so its kernel is enqueued only after that rank's (turn_wait), and says so itself
+    // (turn_done).  With every kernel's producers launched before it, progress does not depend on how the runtime maps the
+    // ranks' streams onto hardware queues (a FIFO shared by two ranks' streams could otherwise put a waiter in front of
+    // its producer).  Transports whose ranks own a device each need neither.
+    virtual int turn_wait(int /*above*/, long /*solve*/) { return PAPOF_OK; }
+    virtual void turn_done(long /*solve*/) {}
 };
 
 struct RcclApi {
@@ -186,7 +203,9 @@ struct LocalGroup {
     long generation = 0;
     bool failed = false;
     std::vector<std::vector<Msg>> posted;
-    explicit LocalGroup(int n_) : n(n_), posted(n_) {}
+    std::vector<void*> arena_base, sync_base;  // bases(): what every rank posted
+    std::vector<long> launched;                // solver kernels of the current call each rank has enqueued (turn_wait)
+    explicit LocalGroup(int n_) : n(n_), posted(n_), arena_base(n_, nullptr), sync_base(n_, nullptr), launched(n_, 0) {}
     bool barrier() {  // false: the group has failed (a rank bailed out, or a rank never arrived)
         std::unique_lock<std::mutex> lk(mu);
         if (failed) return false;
@@ -210,6 +229,37 @@ struct LocalGroup {
 
 struct LocalTransport : Transport {
     std::shared_ptr<LocalGroup> g;
+    int barrier(papof_handle* h) override {
+        if (hipStreamSynchronize(h->stream) != hipSuccess) {
+            g->fail();
+            return PAPOF_EDEVICE;
+        }
+        return g->barrier() ? PAPOF_OK : PAPOF_ETIMEOUT;
+    }
+    int bases(papof_handle* h, void* arena, void* sync, std::vector<void*>& arenas, std::vector<void*>& syncs) override {
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->arena_base[rank] = arena;
+            g->sync_base[rank] = sync;
+            g->launched[rank] = 0;
+        }
+        PAPOF_TRY(barrier(h));  // all posted (same process, same device: the pointers are usable as they are)
+        arenas = g->arena_base;
+        syncs = g->sync_base;
+        return g->barrier() ? PAPOF_OK : PAPOF_ETIMEOUT;  // nobody re-posts before everybody has read
+    }
+    int turn_wait(int above, long solve) override {
+        std::unique_lock<std::mutex> lk(g->mu);
+        if (!g->cv.wait_for(lk, std::chrono::seconds(30), [&] { return g->launched[above] > solve || g->failed; }))
+            g->failed = true;
+        if (g->failed) g->cv.notify_all();
+        return g->failed ? PAPOF_ETIMEOUT : PAPOF_OK;
+    }
+    void turn_done(long solve) override {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->launched[rank] = solve + 1;
+        g->cv.notify_all();
+    }
     int exchange(papof_handle* h, const std::vector<Msg>& sends, const std::vector<Msg>& recvs) override {
         if (hipStreamSynchronize(h->stream) != hipSuccess) {
             g->fail();
@@ -591,6 +641,314 @@ int tiles_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     return PAPOF_OK;
 }
 
+
+// =================================================================================================
+// EXACT-ORDER split of one frame pair over the ranks: horizontal ranges of SOLVER BANDS (BASELINE.json configs[4] with the
+// reference's own sweep order, src/OpticalFlow.cpp:458-505 -- the only way the multi-rank result can meet the 1e-4 parity
+// bar, since any red-black result is 1e-2 away: SURVEY.md F1).  Results are bit-identical to papof_flow_device().
+//
+//   * The solver's bands are time-skewed (band b owns rows 62b - k .. 62b - k + 61 at sweep k, sor.hip), so the cut
+//     between two ranks climbs one row per sweep and a band depends on its upper neighbour only.  Rank g runs the bands
+//     [B_g, B_g+1) of every solve with the plain one-sweep-per-wave kernel in its SPLIT form (sor.hip: ExactArgs): the one
+//     edge that crosses a cut -- lane 62 of band B_g+1 - 1, one 16-byte cell per step -- is stored by the producer straight
+//     into per-sweep inbox cells inside the planes of the rank below, and its progress counter is published there too.
+//     Nothing is reused within a solve, so no write-after-read edge leads back across the cut; the consumer polls and
+//     loads LOCAL memory only.  The solver kernels of all ranks are in flight at the same time and pipeline exactly as
+//     the bands of one launch do.
+//   * Everything else is per-pixel work on ROW RANGES of full-size planes (the kernels of kernels.hip take a Rect or a row
+//     range, as in the 2-D tiles above): rank g assembles the coefficient rows its bands touch over all sweeps,
+//     [62 B_g - K, 62 B_g+1), from blend / imdt rows +-2, warped rows +-4, phi one row more above; replicated read-only
+//     inputs (pyramids, features) are built on every rank.
+//   * After a solve rank g holds the FINAL increments of the rows [62 B_g - (K-1), 62 B_g+1 - (K-1)) -- a partition of
+//     the plane -- adds them to (u, v) there, and the ranks exchange the rows of (u, v) the next iteration's stages read
+//     beyond their own (K + 3 rows from below, 5 from above): ONE exchange per outer iteration (the red-black tiles need 6),
+//     21 per 1080p config-4 pair.
+// Needs directly addressable peer memory (Transport::bases): the LOCAL transport.  [A multi-GPU transport for it must map
+// the neighbour's planes and counters (hipIpc / peer access, fine-grained memory, system-scope stores): DESIGN.md 7.]
+// =================================================================================================
+struct BandSplit {
+    int n, nb, K, lh;
+    int B(int g) const { return nb >= n ? (int)((long long)g * nb / n) : std::min(g, nb); }
+    static int clampi(int x, int hi) { return x < 0 ? 0 : (x > hi ? hi : x); }
+    bool has(int g) const { return B(g + 1) > B(g); }
+    // rows whose final (du, dv) of a solve rank g holds: a partition of [0, lh)
+    void final_rows(int g, int& y0, int& y1) const {
+        if (!has(g)) {
+            y0 = y1 = 0;
+            return;
+        }
+        y0 = B(g) == 0 ? 0 : clampi(kBandRows * B(g) - (K - 1), lh);
+        y1 = B(g + 1) == nb ? lh : clampi(kBandRows * B(g + 1) - (K - 1), lh);
+    }
+    // coefficient rows the tasks of rank g touch over all sweeps (lane 0 of the first band at the last sweep .. lane 62 of
+    // the last band at sweep 0)
+    void coef_rows(int g, int& y0, int& y1) const {
+        if (!has(g)) {
+            y0 = y1 = 0;
+            return;
+        }
+        y0 = clampi(kBandRows * B(g) - K, lh);
+        y1 = clampi(kBandRows * B(g + 1), lh);
+    }
+};
+
+int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, int W, int C, int levels,
+               const papof_params& P, double* d_vx, double* d_vy, double* d_warp, double* timing) {
+    papof_handle* h = t.h;
+    PAPOF_TRY(check_params(P, levels));
+    const int n_sor_max = P.n_sor + (levels - 1) * P.n_sor_per_level;
+    if (P.sor_mode != PAPOF_SOR_EXACT || P.n_inner != 1 || P.interpolation != PAPOF_INTERP_BILINEAR ||
+        P.noise_model != PAPOF_NOISE_LAPLACIAN || n_sor_max > 128 || !h->use_dpp) {
+        set_last_error_text("the exact-order band split takes the default branches with n_inner = 1 and at most 128 sweeps");
+        return PAPOF_EINVAL;
+    }
+    double ratio = P.ratio;
+    if (ratio > 0.98 || ratio < 0.4) ratio = 0.75;
+    std::vector<Level> L;
+    std::vector<PyrPlan> plan;
+    PAPOF_TRY(pyramid_plan(H, W, P.ratio, levels, L, plan));
+    h->seq.valid = false;
+    PAPOF_TRY(ensure_arena(h, arena_bytes_for(H, W, C, levels, n_sor_max, P.ratio) + (size_t)H * W * C * sizeof(double)));
+    Arena& A = h->arena;
+    A.off = 0;
+    A.overflow = false;
+    h->events_used = 0;
+    h->sor_log.clear();
+    t.exchanges = 0;
+    t.exchanged_bytes = 0;
+    const size_t np0 = (size_t)H * W;
+    const int fc = feature_channels(C);
+    const int me = t.tp->rank, n = t.tp->nranks;
+    double tm[PAPOF_N_TIMERS];
+    std::memset(tm, 0, sizeof tm);
+    PhaseClock total{h, true}, sorclk{h, true};
+    total.phase(PAPOF_T_TOTAL);
+
+    // ---- identical allocation sequence on every rank: a buffer sits at the same arena offset everywhere, so a peer's
+    // pointer is its arena base + my offset
+    for (int i = 0; i < levels; i++) {
+        L[i].p1 = A.f64((size_t)L[i].w * L[i].h * C);
+        L[i].p2 = A.f64((size_t)L[i].w * L[i].h * C);
+    }
+    double* tmp_a = A.f64(np0 * C);
+    double* tmp_b = A.f64(np0 * C);
+    std::vector<double*> F1(levels), F2(levels);
+    for (int k = 0; k < levels; k++) {
+        const size_t nn = (size_t)L[k].w * L[k].h * fc;
+        F1[k] = A.f64(nn);
+        F2[k] = A.f64(nn);
+    }
+    double* warp = A.f64(np0 * fc);
+    double* u = A.f64(np0);
+    double* v = A.f64(np0);
+    double* u2 = A.f64(np0);
+    double* v2 = A.f64(np0);
+    double* im1s = A.f64(np0 * fc);
+    double* tmp = A.f64(np0 * fc);
+    double* blend = A.f64(np0 * fc);
+    double* imdt = A.f64(np0 * fc);
+    double* phi = A.f64(np0);
+    double* warp_hwc = A.f64(np0 * C);
+    double* gx = A.f64(np0 * C);
+    double* gy = A.f64(np0 * C);
+    double* gxy = A.f64(np0 * C);
+    SorPlanes sp{};
+    PAPOF_TRY(sor_alloc_planes(A, H, W, PAPOF_SOR_EXACT, n_sor_max, sp));
+    if (A.overflow) return PAPOF_ENOMEM;
+
+    // ---- progress counters of every solve of the call (plain layout), cleared once; then the peers' bases
+    struct LevelCounters {
+        size_t off, per;
+    };
+    std::vector<LevelCounters> LP(levels);
+    size_t prog_total = 0;
+    for (int k = 0; k < levels; k++) {
+        const int Kk = P.n_sor + k * P.n_sor_per_level;
+        LP[k].per = (size_t)skew_dims(L[k].h, L[k].w, Kk, 1, 1).nb * Kk * 32;
+        LP[k].off = prog_total;
+        prog_total += LP[k].per * (size_t)(P.n_outer + k * P.n_outer_per_level);
+        if ((long long)skew_dims(L[k].h, L[k].w, Kk, 1, 1).nb * Kk > 2048) {  // all ranks' tasks of a solve are in flight together
+            set_last_error_text("solve too large for the co-resident band split");
+            return PAPOF_EINVAL;
+        }
+    }
+    PAPOF_TRY(sor_counters_ensure(h, prog_total));
+    if (!sor_counters_clear(h, 0, prog_total)) return PAPOF_EDEVICE;
+    std::vector<void*> arenas, syncs;
+    PAPOF_TRY(t.tp->bases(h, A.base, h->sync_words, arenas, syncs));  // (a barrier: every rank's counters are clear)
+    const auto peer_ptr = [&](int r, const void* mine, const void* my_base, void* peer_base) -> void* {
+        (void)r;
+        return (char*)peer_base + ((const char*)mine - (const char*)my_base);
+    };
+
+    // ---- replicated, flow-independent work on the preparation stream (as tiles_flow)
+    const bool overlap = h->overlap_prep && h->prep_stream != nullptr;
+    while (h->sync_events.size() < (size_t)levels + 2) {
+        hipEvent_t e;
+        PAPOF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->sync_events.push_back(e);
+    }
+    {
+        hipStream_t const main_stream = h->stream;
+        if (overlap) {
+            PAPOF_HIP(hipEventRecord(h->sync_events[levels + 1], main_stream));
+            PAPOF_HIP(hipStreamWaitEvent(h->prep_stream, h->sync_events[levels + 1], 0));
+            h->stream = h->prep_stream;
+        }
+        int rc = hwc_to_planar(h, d_im1, L[0].p1, H, W, C);
+        if (rc == PAPOF_OK) rc = hwc_to_planar(h, d_im2, L[0].p2, H, W, C);
+        if (rc == PAPOF_OK) rc = build_pyramid(h, L, plan, C, false, tmp_a, tmp_b);
+        if (rc == PAPOF_OK) rc = build_pyramid(h, L, plan, C, true, tmp_a, tmp_b);
+        for (int k = levels - 1; k >= 0 && rc == PAPOF_OK; k--) {
+            rc = im2feature(h, L[k].p1, F1[k], L[k].h, L[k].w, C);
+            if (rc == PAPOF_OK) rc = im2feature(h, L[k].p2, F2[k], L[k].h, L[k].w, C);
+            if (rc == PAPOF_OK && overlap && hipEventRecord(h->sync_events[k], h->stream) != hipSuccess) rc = PAPOF_EDEVICE;
+        }
+        if (rc == PAPOF_OK) rc = central3_planes(h, L[0].p2, gx, gy, gxy, H, W, C);
+        if (rc == PAPOF_OK && overlap && hipEventRecord(h->sync_events[levels], h->stream) != hipSuccess) rc = PAPOF_EDEVICE;
+        h->stream = main_stream;
+        if (rc != PAPOF_OK) {
+            if (overlap) hipStreamSynchronize(h->prep_stream);
+            return rc;
+        }
+    }
+
+    const Taps g5 = smooth5_taps();
+    const char* const silent_env = std::getenv("PAPOF_BANDS_SILENT_RANK");  // fault injection (tests): this rank
+    const bool silent = silent_env && std::atoi(silent_env) == me;                 // never launches its solver kernels
+    int pw = 0, ph = 0;
+    long solve_no = 0;  // solves of this call so far (the same number on every rank)
+    BandSplit prev{n, 0, 1, 0};
+    for (int k = levels - 1; k >= 0; k--) {
+        const int lw = L[k].w, lh = L[k].h;
+        const size_t np = (size_t)lw * lh;
+        const int K = P.n_sor + k * P.n_sor_per_level, n_outer = P.n_outer + k * P.n_outer_per_level;
+        PAPOF_TRY(sor_bind_plain(h, sp, lh, lw, K));
+        const BandSplit bs{n, sp.sd.nb, K, lh};
+        const int B0 = bs.B(me), B1 = bs.B(me + 1);
+        const bool mine = B1 > B0;
+        int ra0, ra1;
+        bs.coef_rows(me, ra0, ra1);
+        const auto rows = [&](int y0, int y1) { return Rect{0, std::max(0, y0), lw, std::min(lh, y1)}; };
+        const Rect Rsys = rows(ra0, ra1), Rsm = mine ? rows(ra0 - 2, ra1 + 2) : Rect{0, 0, 0, 0};
+        const Rect Rw = mine ? rows(ra0 - 4, ra1 + 4) : Rect{0, 0, 0, 0}, Rphi = mine ? rows(ra0 - 1, ra1) : Rect{0, 0, 0, 0};
+        const RectOf own = [&](int r) {
+            int y0, y1;
+            bs.final_rows(r, y0, y1);
+            return y1 > y0 ? Rect{0, y0, lw, y1} : Rect{0, 0, 0, 0};
+        };
+        const RectOf need_u = [&](int r) {
+            int y0, y1;
+            bs.coef_rows(r, y0, y1);
+            return y1 > y0 ? Rect{0, std::max(0, y0 - 4), lw, std::min(lh, y1 + 4)} : Rect{0, 0, 0, 0};
+        };
+        const double *f1 = F1[k], *f2 = F2[k];
+        if (overlap) PAPOF_HIP(hipStreamWaitEvent(h->stream, h->sync_events[k], 0));
+        // every non-cell of the coefficient planes is 0.0, and every cell of the (du, dv) planes -- the inbox cells the rank
+        // above writes included -- is finite before anybody reads it (ghost lanes read positions nobody writes)
+        PAPOF_TRY(sor_reset_planes(h, sp));
+        PAPOF_HIP(hipMemsetAsync(sp.du, 0, (sp.sd.nd + sp.sd.nh) * 16, h->stream));
+        if (k == levels - 1) {  // src/OpticalFlow.cpp:801-806
+            PAPOF_HIP(hipMemsetAsync(u, 0, np * sizeof(double), h->stream));
+            PAPOF_HIP(hipMemsetAsync(v, 0, np * sizeof(double), h->stream));
+            PAPOF_HIP(hipMemcpyAsync(warp, f2, np * fc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            PAPOF_TRY(t.tp->barrier(h));  // the planes are clear before a peer's solver kernel may write its inbox cells
+        } else {  // :809-814: the coarser level's final rows -> the rows of it the up-sampling of my rows reads
+            const double xr = (double)lw / pw, yr = (double)lh / ph, inv = 1 / ratio;
+            const int cw = pw, chh = ph;
+            const BandSplit pb = prev;
+            const RectOf own_c = [&](int r) {
+                int y0, y1;
+                pb.final_rows(r, y0, y1);
+                return y1 > y0 ? Rect{0, y0, cw, y1} : Rect{0, 0, 0, 0};
+            };
+            const RectOf need_c = [&](int r) { return resize_source(need_u(r), xr, yr, cw, chh); };
+            double* uv[2] = {u, v};
+            PAPOF_TRY(exchange_planes(t, uv, 2, cw, own_c, need_c));  // (its barrier also orders the clears above)
+            PAPOF_TRY(resize(h, u, u2, ph, pw, 1, lh, lw, xr, yr, true, inv, &Rw));
+            PAPOF_TRY(resize(h, v, v2, ph, pw, 1, lh, lw, xr, yr, true, inv, &Rw));
+            std::swap(u, u2);
+            std::swap(v, v2);
+            PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc, &Rw));
+        }
+        // smoothed features of frame 1 on the rows the blend is needed on (getDxs, src/OpticalFlow.cpp:84-90)
+        PAPOF_TRY(filter_h(h, f1, tmp, lh, lw, fc, g5, &Rw));
+        PAPOF_TRY(filter_v(h, tmp, im1s, lh, lw, fc, g5, &Rsm));
+        // the rank that runs band B1 (the next one with bands: ranks without bands sit at the end)
+        const int below = me + 1 < n && bs.has(me + 1) ? me + 1 : -1;
+        for (int count = 0; count < n_outer; count++) {
+            if (mine) {
+                PAPOF_TRY(smooth_hv_blend(h, warp, im1s, blend, imdt, lh, lw, fc, Rsm.y0, Rsm.y1));
+                PAPOF_TRY(compute_phi(h, u, v, nullptr, phi, lh, lw, &Rphi));
+                PAPOF_TRY(assemble_system(h, blend, imdt, phi, u, v, lh, lw, fc, P.alpha, P.omega, sp, nullptr, nullptr,
+                                          nullptr, &Rsys));
+                unsigned* const prog = h->sync_words + 32 + LP[k].off + (size_t)count * LP[k].per;
+                SorSplit cut{nullptr, nullptr, B0 > 0, below >= 0};
+                if (below >= 0) {
+                    cut.peer_du = (double*)peer_ptr(below, sp.du, A.base, arenas[below]);
+                    cut.peer_prog = (unsigned*)peer_ptr(below, prog, h->sync_words, syncs[below]);
+                }
+                if (B0 > 0) PAPOF_TRY(t.tp->turn_wait(me - 1, solve_no));  // (ranks with bands are 0 .. m: the one above is me - 1)
+                sorclk.phase(PAPOF_T_PHASE5_SOR);
+                if (!silent) PAPOF_TRY(sor_solve_bands(h, sp, lh, lw, P.alpha, P.omega, K, prog, B0, B1, &cut));
+                sorclk.phase(-1);
+                t.tp->turn_done(solve_no);
+                Rect Rf = own(me);
+                // :513-514 on the rows whose final increments this rank holds, into the other pair of planes
+                PAPOF_TRY(update_warp_phi(h, sp, u, v, u2, v2, f1, f2, warp, nullptr, lh, lw, fc, false, Rf.y0, Rf.y1));
+            }
+            solve_no++;
+            std::swap(u, u2);
+            std::swap(v, v2);
+            double* uv[2] = {u, v};
+            PAPOF_TRY(exchange_planes(t, uv, 2, lw, own, need_u));
+            if (mine && count + 1 < n_outer) PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc, &Rw));  // :516
+        }
+        pw = lw;
+        ph = lh;
+        prev = bs;
+    }
+
+    // src/OpticalFlow.cpp:841-842: bicubic warp of the ORIGINAL frame 2 on the rows this rank owns, then everything to rank 0
+    {
+        if (overlap) PAPOF_HIP(hipStreamWaitEvent(h->stream, h->sync_events[levels], 0));
+        const int lw = W, lh = H;
+        const BandSplit pb = prev;
+        const RectOf own = [&](int r) {
+            int y0, y1;
+            pb.final_rows(r, y0, y1);
+            return y1 > y0 ? Rect{0, y0, lw, y1} : Rect{0, 0, 0, 0};
+        };
+        const Rect T = own(me);
+        PAPOF_TRY(bicubic_warp(h, L[0].p1, L[0].p2, gx, gy, gxy, u, v, warp_hwc, H, W, C, &T));
+        const RectOf need = [&](int r) { return r == 0 ? Rect{0, 0, lw, lh} : Rect{0, 0, 0, 0}; };
+        double* uv[2] = {u, v};
+        PAPOF_TRY(exchange_planes(t, uv, 2, W, own, need));
+        const RectOf own_c = [&](int r) {
+            const Rect q = own(r);
+            return Rect{q.x0 * C, q.y0, q.x1 * C, q.y1};
+        };
+        const RectOf need_c = [&](int r) { return r == 0 ? Rect{0, 0, W * C, H} : Rect{0, 0, 0, 0}; };
+        double* wp[1] = {warp_hwc};
+        PAPOF_TRY(exchange_planes(t, wp, 1, W * C, own_c, need_c));
+        if (me == 0) {
+            if (!d_vx || !d_vy || !d_warp) return PAPOF_EINVAL;
+            PAPOF_HIP(hipMemcpyAsync(d_vx, u, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            PAPOF_HIP(hipMemcpyAsync(d_vy, v, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            PAPOF_HIP(hipMemcpyAsync(d_warp, warp_hwc, np0 * C * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
+    total.phase(-1);
+    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    if (overlap) PAPOF_HIP(hipStreamSynchronize(h->prep_stream));
+    PAPOF_TRY(sor_check(h));  // PAPOF_ETIMEOUT when a bounded wait of this rank's tasks expired (a peer that never published)
+    if (total.err != PAPOF_OK || sorclk.err != PAPOF_OK) return PAPOF_EDEVICE;
+    sorclk.collect(tm);
+    total.collect(tm);
+    if (timing) std::memcpy(timing, tm, sizeof tm);
+    return PAPOF_OK;
+}
+
 }  // namespace
 }  // namespace papof
 
@@ -721,7 +1079,11 @@ int papof_tiles_flow_device(papof_tiles* t, const double* d_im1, const double* d
         P.sor_mode = PAPOF_SOR_REDBLACK;
     }
     PAPOF_HIP(hipSetDevice(t->h->device));
-    int rc = tiles_flow(*t, d_im1, d_im2, height, width, c, pyramid_levels, P, d_vx, d_vy, d_warpI2, timing_sec);
+    // PAPOF_SOR_EXACT: the exact-order split into horizontal ranges of solver bands over ALL ranks (the rows x cols grid is
+    // the red-black tiles'); anything else: the 2-D tiles
+    int rc = P.sor_mode == PAPOF_SOR_EXACT
+                 ? bands_flow(*t, d_im1, d_im2, height, width, c, pyramid_levels, P, d_vx, d_vy, d_warpI2, timing_sec)
+                 : tiles_flow(*t, d_im1, d_im2, height, width, c, pyramid_levels, P, d_vx, d_vy, d_warpI2, timing_sec);
     if (rc != PAPOF_OK)
         if (auto* lt = dynamic_cast<LocalTransport*>(t->tp.get())) lt->g->fail();  // release the sibling threads
     return rc;

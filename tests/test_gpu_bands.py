@@ -1,0 +1,123 @@
+"""The EXACT-ORDER split of one frame pair over several ranks (csrc/tiles.hip: bands_flow; sor.hip: the SPLIT form of
+k_sor_exact) on ONE GPU: all ranks are threads of this process, each with its own handle, arena, counters and streams
+(LOCAL transport), and the solver kernel of a rank writes the one cell per step that crosses a cut -- and its progress --
+straight into the planes and counters of the rank below.  Unlike the red-black tiles this keeps the reference's own sweep
+order (src/OpticalFlow.cpp:458-505), so the result must be the REFERENCE's bits: compared here with the goldens the
+untouched reference produced (1920x1080 config-4 schedule, 960x540 reference schedule), with the one-GPU exact call, and
+with the oracle."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from papteam_opticalflow_amd import Papof
+    g = Papof(0)
+    yield g
+    g.close()
+
+
+def _params(**kw):
+    from papteam_opticalflow_amd import default_params
+    kw.setdefault("sor_mode", 0)
+    return default_params(**kw)
+
+
+def _run(nranks, a, b, levels, P):
+    from papteam_opticalflow_amd.capi import LocalTileGroup
+    grp = LocalTileGroup(nranks, nranks, 1, 0)
+    try:
+        out = grp.coarse2fine_flow(a, b, levels, P)
+        stats = grp.ranks[0].stats()
+    finally:
+        grp.close()
+    return out, stats
+
+
+@pytest.mark.parametrize("nranks", [2, 8])
+@pytest.mark.parametrize("case,res,levels,kw", [
+    ("cfg4_1920_L5", "1920", 5, dict(n_outer=3, n_outer_per_level=0, n_sor=30, n_sor_per_level=0)),
+    ("e2e_960_L5", "960", 5, {}),
+])
+def test_band_split_returns_the_reference_bits(case, res, levels, kw, nranks):
+    """whole calls with 2 and 8 ranks, array_equal to the reference's goldens: the SHA-256 of the
+    full float64 arrays the untouched reference produced (golden.json), not only the strided subsample."""
+    a, b = cases.load_pair(res)
+    (vx, vy, wi, t), (n_ex, n_bytes) = _run(nranks, a, b, levels, _params(**kw))
+    man = json.load(open(os.path.join(GOLD, "golden.json")))["cases"][case]
+    gold = np.load(os.path.join(GOLD, "golden.npz"))
+    for name, got in (("vx", vx), ("vy", vy), ("warpI2", wi)):
+        assert np.array_equal(cases.subsample(got), gold["%s|%s" % (case, name)]), \
+            "%s/%s: max-abs %.3e vs the reference's subsample" % (case, name, np.abs(cases.subsample(got) - gold["%s|%s" % (case, name)]).max())
+        assert cases.sha(got) == man[name]["sha"], "%s/%s: full-array SHA-256 differs from the reference's" % (case, name)
+    n_solves = sum((kw.get("n_outer", 7) + k * kw.get("n_outer_per_level", 1)) for k in range(levels))
+    assert n_ex == n_solves + (levels - 1) + 2  # one (u, v) exchange per outer iteration, level changes, the final gather
+    assert t[9] > 0 and t[6] > 0
+    print("exact-order band split, %d ranks, %s: %d exchanges, %.1f MB moved by rank 0, SOR %.2f ms of %.2f ms on one device" %
+          (nranks, case, n_ex, n_bytes / 1e6, t[6] * 1e3, t[9] * 1e3))
+
+
+@pytest.mark.parametrize("nranks,res,levels,kw", [
+    (3, "240", 5, {}),                                                       # coarse levels have fewer bands than ranks
+    (8, "240", 4, dict(n_outer=2, n_outer_per_level=1, n_sor=9, n_sor_per_level=4)),   # 135 rows: at most 3 bands for 8 ranks
+    (5, "480", 3, dict(n_outer=2, n_outer_per_level=0, n_sor=70, n_sor_per_level=5)),  # more sweeps than rows per band
+    (2, "480", 5, dict(n_outer=3, n_outer_per_level=0, n_sor=30, n_sor_per_level=0, alpha=0.02, omega=1.5)),
+    (1, "240", 3, {}),
+])
+def test_band_split_equals_one_gpu_exact_call(gpu, nranks, res, levels, kw):
+    a, b = cases.load_pair(res)
+    P = _params(**kw)
+    want = gpu.coarse2fine_flow(a, b, levels, P)[:3]
+    (vx, vy, wi, _), _ = _run(nranks, a, b, levels, P)
+    for name, g, w in zip(("vx", "vy", "warpI2"), (vx, vy, wi), want):
+        assert np.array_equal(g, w), "%d ranks %s L%d %s %s: max-abs %.3e" % (nranks, res, levels, kw, name, np.abs(g - w).max())
+
+
+def test_band_split_ragged_frame_matches_oracle(oracle):
+    a, b = cases.load_pair("480")
+    a = np.ascontiguousarray(a[:203, :311])
+    b = np.ascontiguousarray(b[:203, :311])
+    kw = dict(n_outer=2, n_outer_per_level=1, n_sor=11, n_sor_per_level=2)
+    (vx, vy, wi, _), _ = _run(4, a, b, 3, _params(**kw))
+    p = oracle.default_params()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    ow = oracle.coarse2fine_flow(a, b, 3, p)[:3]
+    for name, g, w in zip(("vx", "vy", "warpI2"), (vx, vy, wi), ow):
+        assert np.array_equal(g, w), "%s: max-abs %.3e" % (name, np.abs(g - w).max())
+
+
+def test_band_split_rejects_what_it_does_not_cover(gpu):
+    from papteam_opticalflow_amd import PapofError
+    a, b = cases.load_pair("240")
+    for kw in (dict(n_inner=2), dict(interpolation=1), dict(noise_model=1), dict(n_sor=129)):
+        with pytest.raises(PapofError):
+            _run(2, a, b, 2, _params(**kw))
+
+
+def test_a_peer_that_never_publishes_ends_in_a_timeout_not_a_hang(monkeypatch):
+    """The bounded waits across the cut: rank 0 never launches its solver kernels (PAPOF_BANDS_SILENT_RANK), so the first
+    band of rank 1 never sees progress of the band above it.  Its tasks must give up after their bounded spin, raise their
+    rank's abort word -- every other task of that rank ends when it sees it -- and the call must come back with
+    PAPOF_ETIMEOUT (-5) within seconds instead of hanging or returning numbers as if nothing had happened."""
+    import time
+    from papteam_opticalflow_amd import PapofError
+    a, b = cases.load_pair("480")
+    monkeypatch.setenv("PAPOF_BANDS_SILENT_RANK", "0")
+    t0 = time.time()
+    with pytest.raises(PapofError) as err:
+        _run(2, a, b, 1, _params(n_outer=1, n_outer_per_level=0, n_sor=5, n_sor_per_level=0))
+    assert err.value.code == -5, err.value
+    assert time.time() - t0 < 120
+    monkeypatch.delenv("PAPOF_BANDS_SILENT_RANK")
+    (vx, vy, wi, _), _ = _run(2, a, b, 1, _params(n_outer=1, n_outer_per_level=0, n_sor=5, n_sor_per_level=0))  # and works afterwards
+    assert np.isfinite(vx).all()

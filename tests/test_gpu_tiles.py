@@ -120,10 +120,12 @@ def test_config5_1920x1080_2x4_tiles_at_size(gpu, oracle):
           (n_ex, n_bytes / 1e6, t[9] * 1e3))
 
 
-def test_tiled_rejects_exact_order_and_inner_iterations(gpu):
+def test_tiled_rejects_jacobi_and_inner_iterations(gpu):
+    """(sor_mode = 0, the reference's own order, is no longer rejected: it runs as the exact-order split into ranges of
+    solver bands, tests/test_gpu_bands.py)"""
     from papteam_opticalflow_amd import PapofError
     a, b = cases.load_pair("240")
-    for kw in (dict(sor_mode=0), dict(n_inner=2)):
+    for kw in (dict(sor_mode=2), dict(n_inner=2)):
         with pytest.raises(PapofError):
             _run_tiles(2, 1, 2, 4, a, b, 2, _params(**kw))
 
