@@ -852,12 +852,83 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         if (overlap) PAPOF_HIP(hipEventRecord(h->sync_events[levels], prep));
         return PAPOF_OK;
     };
+    // Host buffers (flow_host): the uploads are queued from HERE, on the copy stream, in an order that lets frame 1's whole
+    // share of the preparation -- planarise, its pyramid, its features and their smoothing on every level -- run while frame
+    // 2 is still crossing PCIe (0.9 ms per 1080p float64 frame); only frame 2's share (coarsest level first, one event per
+    // level) is left when the upload ends, and less streaming work runs beside the coarse levels' solves.  Same kernels, same
+    // inputs: same bits.  [The device-resident call keeps the level-interleaved order above: there the main stream starts
+    // the coarsest level as early as possible.]
+    papof_handle::HostIO& io = h->hostio;
+    const bool hostio = io.active && overlap && !in_capture && h->copy_stream && h->copy_events.size() >= 8;
+    const auto prepare_hostio = [&]() -> int {
+        StreamSwap on_prep(h, prep);
+        hipStream_t const cs = h->copy_stream;
+        pclk.phase(PAPOF_T_ALLOCATION);
+        if (exact && !sor_counters_clear(h, 0, prog_total)) return PAPOF_EDEVICE;
+        bool from_level0 = true;
+        for (int i = 1; i < levels; i++) from_level0 = from_level0 && plan[i].src_level == 0;
+        const Taps g5 = smooth5_taps();
+        const auto build_level = [&](int i, int second) -> int {
+            if (i == 0) return PAPOF_OK;
+            const PyrPlan& q = plan[i];
+            const double* src = second ? L[q.src_level].p2 : L[q.src_level].p1;
+            double* dst = second ? L[i].p2 : L[i].p1;
+            return smooth_and_resize(h, src, dst, tmp_a, tmp_b, q, C, L[i].h, L[i].w);
+        };
+        // ---- frame 1: upload (this call may hold the host until the bytes are staged), then its whole share
+        if (io.im1) {
+            PAPOF_HIP(hipMemcpyAsync(const_cast<void*>(fa.d), io.im1, io.nb_in, hipMemcpyHostToDevice, cs));
+            PAPOF_HIP(hipEventRecord(h->copy_events[0], cs));
+            PAPOF_HIP(hipStreamWaitEvent(prep, h->copy_events[0], 0));
+        }
+        pclk.phase(PAPOF_T_CONSTRUCTION);
+        if (op != kSeqNext) {
+            PAPOF_TRY(load_frame(h, fa, L[0].p1, H, W, C));
+            for (int i = 1; i < levels; i++) PAPOF_TRY(build_level(i, 0));
+        }
+        for (int k = levels - 1; k >= 0; k--) {
+            pclk.phase(PAPOF_T_ALLOCATION);
+            PAPOF_TRY(im2feature(h, L[k].p1, F1[k], L[k].h, L[k].w, C));
+            pclk.phase(PAPOF_T_PHASE1_GENERATE);
+            PAPOF_TRY(filter_hv(h, F1[k], S1[k], prep_tmp, L[k].h, L[k].w, fc, g5, g5));
+        }
+        pclk.phase(-1);
+        // ---- frame 2: upload beside the kernels just queued, then its share, coarsest level first
+        if (io.im2) {
+            PAPOF_HIP(hipMemcpyAsync(const_cast<void*>(fb.d), io.im2, io.nb_in, hipMemcpyHostToDevice, cs));
+            PAPOF_HIP(hipEventRecord(h->copy_events[1], cs));
+            PAPOF_HIP(hipStreamWaitEvent(prep, h->copy_events[1], 0));
+        }
+        pclk.phase(PAPOF_T_CONSTRUCTION);
+        PAPOF_TRY(load_frame(h, fb, L[0].p2, H, W, C));
+        if (!from_level0)
+            for (int i = 1; i < levels; i++) PAPOF_TRY(build_level(i, 1));
+        for (int k = levels - 1; k >= 0; k--) {
+            if (from_level0) {
+                pclk.phase(PAPOF_T_CONSTRUCTION);
+                PAPOF_TRY(build_level(k, 1));
+            }
+            pclk.phase(PAPOF_T_ALLOCATION);
+            PAPOF_TRY(im2feature(h, L[k].p2, F2[k], L[k].h, L[k].w, C));
+            pclk.phase(-1);
+            PAPOF_HIP(hipEventRecord(h->sync_events[k], prep));
+        }
+        pclk.phase(PAPOF_T_POSTPROCESSING);
+        PAPOF_TRY(central3_planes(h, L[0].p2, gx, gy, gxy, H, W, C));
+        pclk.phase(-1);
+        PAPOF_HIP(hipEventRecord(h->sync_events[levels], prep));
+        return PAPOF_OK;
+    };
+    if (io.active && !hostio) {  // the caller left the uploads to this call, which cannot overlap them: plain copies, in order
+        if (io.im1) PAPOF_HIP(hipMemcpyAsync(const_cast<void*>(fa.d), io.im1, io.nb_in, hipMemcpyHostToDevice, main_stream));
+        if (io.im2) PAPOF_HIP(hipMemcpyAsync(const_cast<void*>(fb.d), io.im2, io.nb_in, hipMemcpyHostToDevice, main_stream));
+    }
     if (overlap) {  // the preparation starts after whatever the caller queued on the main stream (the frame uploads)
         PAPOF_HIP(hipEventRecord(h->sync_events[levels + 1], main_stream));
         PAPOF_HIP(hipStreamWaitEvent(prep, h->sync_events[levels + 1], 0));
     }
     {
-        const int rc = prepare();
+        const int rc = hostio ? prepare_hostio() : prepare();
         if (rc != PAPOF_OK) {
             if (in_capture) {
                 hipGraph_t graph = nullptr;
@@ -938,6 +1009,27 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         clk.phase(-1);
         if (overlap) PAPOF_HIP(hipStreamWaitEvent(main_stream, h->sync_events[levels], 0));
         clk.phase(PAPOF_T_POSTPROCESSING);  // src/OpticalFlow.cpp:841-842
+        if (hostio && io.early_out && u == d_vx && v == d_vy) {
+            // page-locked result arrays: (vx, vy) are final -- their copies run beside the bicubic warp -- and warpI2 follows
+            // its kernel in row chunks (the kernel takes a Rect; rows of the interleaved image are contiguous)
+            hipStream_t const cs = h->copy_stream;
+            PAPOF_HIP(hipEventRecord(h->copy_events[2], main_stream));
+            PAPOF_HIP(hipStreamWaitEvent(cs, h->copy_events[2], 0));
+            PAPOF_HIP(hipMemcpyAsync(io.vx, d_vx, io.nb_flow, hipMemcpyDeviceToHost, cs));
+            PAPOF_HIP(hipMemcpyAsync(io.vy, d_vy, io.nb_flow, hipMemcpyDeviceToHost, cs));
+            constexpr int kChunks = 4;
+            for (int q = 0; q < kChunks; q++) {
+                const Rect rc{0, (int)((long long)H * q / kChunks), W, (int)((long long)H * (q + 1) / kChunks)};
+                if (rc.empty()) continue;
+                PAPOF_TRY(bicubic_warp(h, L[0].p1, L[0].p2, gx, gy, gxy, u, v, d_warp, H, W, C, &rc));
+                PAPOF_HIP(hipEventRecord(h->copy_events[3 + q], main_stream));
+                PAPOF_HIP(hipStreamWaitEvent(cs, h->copy_events[3 + q], 0));
+                const size_t off = (size_t)rc.y0 * W * C, cnt = (size_t)rc.h() * W * C;
+                PAPOF_HIP(hipMemcpyAsync(io.warp + off, d_warp + off, cnt * sizeof(double), hipMemcpyDeviceToHost, cs));
+            }
+            io.out_issued = true;
+            return PAPOF_OK;
+        }
         PAPOF_TRY(bicubic_warp(h, L[0].p1, L[0].p2, gx, gy, gxy, u, v, d_warp, H, W, C));
         if (u != d_vx) PAPOF_HIP(hipMemcpyAsync(d_vx, u, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         if (v != d_vy) PAPOF_HIP(hipMemcpyAsync(d_vy, v, np0 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -1155,6 +1247,11 @@ void papof_destroy(papof_handle* h) {
     for (papof::GraphEntry& e : h->graphs)
         if (e.exec) hipGraphExecDestroy(e.exec);
     if (h->prep_stream) hipStreamDestroy(h->prep_stream);
+    if (h->copy_stream) {
+        hipStreamSynchronize(h->copy_stream);
+        hipStreamDestroy(h->copy_stream);
+    }
+    for (hipEvent_t e : h->copy_events) hipEventDestroy(e);
     if (h->arena.base) hipFree(h->arena.base);
     if (h->sync_words) hipFree(h->sync_words);
     if (h->stage_dev) hipFree(h->stage_dev);
@@ -1370,7 +1467,34 @@ int flow_host(papof_handle* h, const void* im1, const void* im2, bool u8, SeqOp 
     // host_copy = 1: the runtime's own pageable path (measured 55 GB/s both ways on this platform: hipMemcpyAsync from / to
     // pageable memory); 0: our pinned bounce pipeline (pageable -> pinned by a thread pool, DMA per 8-MiB chunk)
     const bool plain = h->host_copy == 1;
-    if (plain) {
+    // PAPOF_HOSTIO=0: the copies around the call as in round 2 (A/B); default: the call issues them itself where they overlap
+    // device work (common.h: HostIO).  Not in graph mode (a captured call replays fixed pointers) and not for a priming push.
+    static const bool hostio_env = !(std::getenv("PAPOF_HOSTIO") && std::atoi(std::getenv("PAPOF_HOSTIO")) == 0);
+    bool use_io = plain && hostio_env && !h->use_graph && op != kSeqPrime && h->overlap_prep && h->prep_stream;
+    if (use_io && !h->copy_stream) {
+        if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) h->copy_stream = nullptr;
+        while (h->copy_stream && h->copy_events.size() < 8) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
+            h->copy_events.push_back(e);
+        }
+    }
+    use_io = use_io && h->copy_stream && h->copy_events.size() >= 8;
+    if (use_io) {
+        papof_params Pq;
+        if (params)
+            Pq = *params;
+        else
+            papof_default_params(&Pq);
+        use_io = Pq.phase_timing != 1;  // one-stream timing mode: nothing overlaps by definition
+    }
+    if (use_io) {
+        h->hostio = papof_handle::HostIO{};
+        h->hostio.active = true;
+        h->hostio.im1 = op != kSeqNext ? im1 : nullptr;
+        h->hostio.im2 = im2;
+        h->hostio.nb_in = nb_in;
+    } else if (plain) {
         if (op != kSeqNext) PAPOF_HIP(hipMemcpyAsync(d1, im1, nb_in, hipMemcpyHostToDevice, h->stream));
         if (op != kSeqPrime) PAPOF_HIP(hipMemcpyAsync(d2, im2, nb_in, hipMemcpyHostToDevice, h->stream));
     } else {
@@ -1388,7 +1512,16 @@ int flow_host(papof_handle* h, const void* im1, const void* im2, bool u8, SeqOp 
         return a.type == hipMemoryTypeHost;
     };
     std::thread prefault;
-    if (op != kSeqPrime && np * sizeof(double) >= (size_t(1) << 20) && !(is_pinned(warpI2) && is_pinned(vx) && is_pinned(vy)))
+    const bool out_pinned = op != kSeqPrime && is_pinned(warpI2) && is_pinned(vx) && is_pinned(vy);
+    if (use_io) {
+        h->hostio.vx = vx;
+        h->hostio.vy = vy;
+        h->hostio.warp = warpI2;
+        h->hostio.nb_flow = nb_flow;
+        h->hostio.nb_img = nb_img;
+        h->hostio.early_out = out_pinned;
+    }
+    if (op != kSeqPrime && np * sizeof(double) >= (size_t(1) << 20) && !out_pinned)
         prefault = std::thread([=] {
             const auto touch = [](double* p, size_t bytes) {
                 volatile char* q = reinterpret_cast<volatile char*>(p);
@@ -1401,8 +1534,21 @@ int flow_host(papof_handle* h, const void* im1, const void* im2, bool u8, SeqOp 
         });
     const int rc_dev = device_call(h, FrameIn{d1, u8}, FrameIn{d2, u8}, op, height, width, c, pyramid_levels, params, dx,
                                    dy, dw, tm);
+    const bool out_issued = use_io && h->hostio.out_issued;
+    h->hostio.active = false;
+    if (use_io && h->copy_stream && hipStreamSynchronize(h->copy_stream) != hipSuccess && rc_dev == PAPOF_OK) {
+        if (prefault.joinable()) prefault.join();
+        return PAPOF_EDEVICE;
+    }
     if (prefault.joinable()) prefault.join();
     PAPOF_TRY(rc_dev);
+    if (out_issued) {  // the result copies were queued by the call itself and have landed
+        if (timing_sec) {
+            tm[PAPOF_T_TOTAL] = wall() - t0;
+            std::memcpy(timing_sec, tm, sizeof tm);
+        }
+        return PAPOF_OK;
+    }
     if (op == kSeqPrime) {
         if (timing_sec) std::memcpy(timing_sec, tm, sizeof tm);
         return PAPOF_OK;

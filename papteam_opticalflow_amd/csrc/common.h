@@ -278,6 +278,20 @@ struct papof_handle {
     // second stream for everything that does not depend on the flow (pyramids, features, smoothed frame 1 of every
     // level, derivative planes of the final bicubic warp): runs beside the coarse levels' latency-bound solves
     hipStream_t prep_stream = nullptr;
+    // Host buffers handed to the call itself (flow_host -> flow_device): the call then issues the PCIe copies where they
+    // overlap device work -- frame 2 uploads while frame 1's share of the preparation runs, (vx, vy) go back beside the
+    // final bicubic warp, warpI2 in row chunks behind its kernel's chunks -- on a stream of their own.
+    struct HostIO {
+        bool active = false;
+        const void *im1 = nullptr, *im2 = nullptr;  // null: that frame is already on the device (sequence mode)
+        size_t nb_in = 0;                           // bytes per input frame
+        double *vx = nullptr, *vy = nullptr, *warp = nullptr;
+        size_t nb_flow = 0, nb_img = 0;
+        bool early_out = false;                     // the result arrays are page-locked: their copies may be queued early
+        bool out_issued = false;                    // set by the call when it has queued the result copies itself
+    } hostio;
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> copy_events;
     std::vector<hipEvent_t> sync_events;  // untimed events ordering the two streams
     bool overlap_prep = true;
     // phase stamps (flow_internal.h: PhaseClock): slots the kernels write the 100 MHz clock into
