@@ -108,6 +108,7 @@ struct Transport {
         return PAPOF_EINVAL;
     }
     virtual int barrier(papof_handle*) { return PAPOF_EINVAL; }
+    virtual bool addresses_peers() const { return false; }  // may a kernel of this rank store into a peer's memory?
     // Host-side launch order of the ranks' solver kernels of one solve (bands_flow): rank r's tasks spin on counters that
     // the rank above publishes, so its kernel is enqueued only after that rank's (turn_wait), and says so itself
     // (turn_done).  With every kernel's producers launched before it, progress does not depend on how the runtime maps the
@@ -183,6 +184,7 @@ struct RcclTransport : Transport {
         PAPOF_NCCL(api, api->CommUserRank(comm, r));
         return PAPOF_OK;
     }
+    int barrier(papof_handle*) override { return PAPOF_OK; }  // every rank writes only its own memory: nothing to order
     int exchange(papof_handle* h, const std::vector<Msg>& sends, const std::vector<Msg>& recvs) override {
         if (sends.empty() && recvs.empty()) return PAPOF_OK;
         PAPOF_NCCL(api, api->GroupStart());
@@ -229,6 +231,9 @@ struct LocalGroup {
 
 struct LocalTransport : Transport {
     std::shared_ptr<LocalGroup> g;
+    // PAPOF_BANDS_STAGED=1: behave like a transport without peer addressing, so that the staged protocol the RCCL transport
+    // runs (bands_flow) is exercised on the one-GPU box
+    bool addresses_peers() const override { return !(std::getenv("PAPOF_BANDS_STAGED") && std::atoi(std::getenv("PAPOF_BANDS_STAGED"))); }
     int barrier(papof_handle* h) override {
         if (hipStreamSynchronize(h->stream) != hipSuccess) {
             g->fail();
@@ -317,6 +322,25 @@ __global__ void k_rects(MsgTable t, double* __restrict__ buf) {
         *slot = *cell;
     else
         *cell = *slot;
+}
+
+// The cells that cross a cut of the exact-order band split, as one message (staged protocol of bands_flow): for sweep k and
+// position p the 16-byte cell k >> 1 of block `band` at parity k & 1 of banded (du, dv) planes (sor.hip: ExactArgs) <->
+// msg[k * npos + p].  PACK reads the producer's outbox planes, else the cells go into the consumer's planes.
+template <bool PACK>
+__global__ void k_cut_cells(double2* __restrict__ planes, double2* __restrict__ msg, int nb, int npos, int band, int K) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (p >= npos || k >= K) return;
+    const size_t cell = (size_t)(k & 1) * npos * nb * kLanes + ((size_t)p * nb + band) * kLanes + (size_t)(k >> 1);
+    if (PACK)
+        msg[(size_t)k * npos + p] = planes[cell];
+    else
+        planes[cell] = msg[(size_t)k * npos + p];
+}
+// ... and the producer's progress counters as the consumer then finds them: every sweep of the band above complete
+__global__ void k_cut_counters(unsigned* __restrict__ prog, int nb, int band, int K, unsigned steps) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) prog[((size_t)k * nb + band) * 32] = steps;
 }
 
 }  // namespace
@@ -774,8 +798,31 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     }
     PAPOF_TRY(sor_counters_ensure(h, prog_total));
     if (!sor_counters_clear(h, 0, prog_total)) return PAPOF_EDEVICE;
-    std::vector<void*> arenas, syncs;
-    PAPOF_TRY(t.tp->bases(h, A.base, h->sync_words, arenas, syncs));  // (a barrier: every rank's counters are clear)
+    // DIRECT: the producer's kernel stores the cut cells and its progress into the consumer's memory while both run (needs
+    // peer addressing: the LOCAL transport).  STAGED (any transport, RCCL included): the same SPLIT kernels, but a rank's
+    // kernel writes the cut cells into an OUTBOX of its own, and after it has finished they travel as one message per solve
+    // and cut (n_sor x positions cells, ~1 MB at 1080p) to the rank below, which unpacks them into its inbox cells, marks the
+    // band above complete in its counters and only then launches its own bands: ranks take turns within a solve -- correct
+    // by construction with nothing but sends and receives at kernel boundaries, and necessarily slower than one GPU for the
+    // solver's share (the exact-order solve is one dependency chain); everything else still splits over the ranks.
+    const bool direct = t.tp->addresses_peers();
+    std::vector<void*> arenas(n, nullptr), syncs(n, nullptr);
+    double* outbox = nullptr;       // STAGED: banded planes (same layout) that receive the SPLIT kernel's peer stores
+    unsigned* outprog = nullptr;    // ... and its peer publications (discarded)
+    double* cutmsg = nullptr;       // the packed message (send side and receive side use it in turn)
+    if (direct) {
+        PAPOF_TRY(t.tp->bases(h, A.base, h->sync_words, arenas, syncs));  // (a barrier: every rank's counters are clear)
+    } else {
+        size_t cells = 0, cells_d = 0;
+        skew_capacity(H, W, n_sor_max, cells, cells_d);
+        outbox = A.f64(2 * (cells_d + kLanes));
+        const int npos_max = skew_dims(H, W, n_sor_max, 1, 1).npos_d;
+        cutmsg = A.f64((size_t)2 * n_sor_max * npos_max);
+        size_t per_max = 0;
+        for (int k = 0; k < levels; k++) per_max = std::max(per_max, LP[k].per);
+        outprog = reinterpret_cast<unsigned*>(A.f64(per_max / 2 + 64));
+        if (A.overflow) return PAPOF_ENOMEM;
+    }
     const auto peer_ptr = [&](int r, const void* mine, const void* my_base, void* peer_base) -> void* {
         (void)r;
         return (char*)peer_base + ((const char*)mine - (const char*)my_base);
@@ -848,6 +895,7 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
         // above writes included -- is finite before anybody reads it (ghost lanes read positions nobody writes)
         PAPOF_TRY(sor_reset_planes(h, sp));
         PAPOF_HIP(hipMemsetAsync(sp.du, 0, (sp.sd.nd + sp.sd.nh) * 16, h->stream));
+        if (outbox) PAPOF_HIP(hipMemsetAsync(outbox, 0, (sp.sd.nd + sp.sd.nh) * 16, h->stream));  // (packed whole: finite everywhere)
         if (k == levels - 1) {  // src/OpticalFlow.cpp:801-806
             PAPOF_HIP(hipMemsetAsync(u, 0, np * sizeof(double), h->stream));
             PAPOF_HIP(hipMemsetAsync(v, 0, np * sizeof(double), h->stream));
@@ -884,15 +932,59 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
                                           nullptr, &Rsys));
                 unsigned* const prog = h->sync_words + 32 + LP[k].off + (size_t)count * LP[k].per;
                 SorSplit cut{nullptr, nullptr, B0 > 0, below >= 0};
-                if (below >= 0) {
+                if (below >= 0 && direct) {
                     cut.peer_du = (double*)peer_ptr(below, sp.du, A.base, arenas[below]);
                     cut.peer_prog = (unsigned*)peer_ptr(below, prog, h->sync_words, syncs[below]);
+                } else if (below >= 0) {
+                    cut.peer_du = outbox;
+                    cut.peer_prog = outprog;
                 }
-                if (B0 > 0) PAPOF_TRY(t.tp->turn_wait(me - 1, solve_no));  // (ranks with bands are 0 .. m: the one above is me - 1)
-                sorclk.phase(PAPOF_T_PHASE5_SOR);
-                if (!silent) PAPOF_TRY(sor_solve_bands(h, sp, lh, lw, P.alpha, P.omega, K, prog, B0, B1, &cut));
-                sorclk.phase(-1);
-                t.tp->turn_done(solve_no);
+                if (direct) {
+                    if (B0 > 0) PAPOF_TRY(t.tp->turn_wait(me - 1, solve_no));  // (ranks with bands are 0 .. m: the one above is me - 1)
+                    sorclk.phase(PAPOF_T_PHASE5_SOR);
+                    if (!silent) PAPOF_TRY(sor_solve_bands(h, sp, lh, lw, P.alpha, P.omega, K, prog, B0, B1, &cut));
+                    sorclk.phase(-1);
+                    t.tp->turn_done(solve_no);
+                }
+            }
+            if (!direct) {  // STAGED: round r hands the cut cells of rank r's finished bands to rank r + 1
+                const int m_ranks = std::min(n, sp.sd.nb);  // ranks with bands: 0 .. m_ranks - 1
+                const int npos = sp.sd.npos_d;
+                const size_t msg_doubles = (size_t)2 * K * npos;
+                unsigned* const prog = h->sync_words + 32 + LP[k].off + (size_t)count * LP[k].per;
+                SorSplit cut{below >= 0 ? outbox : nullptr, below >= 0 ? outprog : nullptr, B0 > 0, below >= 0};
+                const dim3 cgrid((npos + 255) / 256, K), cblock(256);
+                const auto solve_mine = [&]() -> int {
+                    sorclk.phase(PAPOF_T_PHASE5_SOR);
+                    if (!silent) PAPOF_TRY(sor_solve_bands(h, sp, lh, lw, P.alpha, P.omega, K, prog, B0, B1, &cut));
+                    sorclk.phase(-1);
+                    return PAPOF_OK;
+                };
+                if (mine && me == 0) PAPOF_TRY(solve_mine());
+                for (int r = 0; r + 1 < m_ranks; r++) {
+                    std::vector<Msg> sends, recvs;
+                    if (me == r) {
+                        hipLaunchKernelGGL(k_cut_cells<true>, cgrid, cblock, 0, h->stream, (double2*)outbox, (double2*)cutmsg,
+                                           sp.sd.nb, npos, B1 - 1, K);
+                        PAPOF_HIP(hipGetLastError());
+                        sends.push_back(Msg{r + 1, cutmsg, msg_doubles});
+                    } else if (me == r + 1) {
+                        recvs.push_back(Msg{r, cutmsg, msg_doubles});
+                    }
+                    PAPOF_TRY(t.tp->exchange(h, sends, recvs));
+                    t.exchanges++;
+                    t.exchanged_bytes += (sends.size() + recvs.size()) * msg_doubles * sizeof(double);
+                    if (me == r + 1) {
+                        hipLaunchKernelGGL(k_cut_cells<false>, cgrid, cblock, 0, h->stream, (double2*)sp.du, (double2*)cutmsg,
+                                           sp.sd.nb, npos, B0 - 1, K);
+                        hipLaunchKernelGGL(k_cut_counters, dim3((K + 63) / 64), dim3(64), 0, h->stream, prog, sp.sd.nb, B0 - 1, K,
+                                           (unsigned)sp.sd.ns);
+                        PAPOF_HIP(hipGetLastError());
+                        PAPOF_TRY(solve_mine());
+                    }
+                }
+            }
+            if (mine) {
                 Rect Rf = own(me);
                 // :513-514 on the rows whose final increments this rank holds, into the other pair of planes
                 PAPOF_TRY(update_warp_phi(h, sp, u, v, u2, v2, f1, f2, warp, nullptr, lh, lw, fc, false, Rf.y0, Rf.y1));

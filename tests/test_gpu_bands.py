@@ -96,6 +96,48 @@ def test_band_split_ragged_frame_matches_oracle(oracle):
         assert np.array_equal(g, w), "%s: max-abs %.3e" % (name, np.abs(g - w).max())
 
 
+@pytest.mark.parametrize("nranks,res,levels,kw", [
+    (2, "960", 5, dict(n_outer=3, n_outer_per_level=0, n_sor=30, n_sor_per_level=0)),
+    (8, "480", 5, {}),
+    (3, "240", 4, dict(n_outer=2, n_outer_per_level=1, n_sor=9, n_sor_per_level=4)),
+])
+def test_staged_protocol_of_the_rccl_transport_gives_the_same_bits(gpu, monkeypatch, nranks, res, levels, kw):
+    """Transports that cannot address peer memory from a kernel (RCCL) run the split STAGED: a rank's kernel writes the cut
+    cells into an outbox of its own, they travel as one message per solve and cut, and the rank below launches its bands
+    after unpacking them (tiles.hip: bands_flow).  PAPOF_BANDS_STAGED=1 makes the LOCAL transport behave that way, so the
+    code the RCCL transport runs -- everything but ncclSend / ncclRecv themselves -- is checked here bit for bit."""
+    monkeypatch.setenv("PAPOF_BANDS_STAGED", "1")
+    a, b = cases.load_pair(res)
+    P = _params(**kw)
+    want = gpu.coarse2fine_flow(a, b, levels, P)[:3]
+    (vx, vy, wi, _), (n_ex, _) = _run(nranks, a, b, levels, P)
+    for name, g, w in zip(("vx", "vy", "warpI2"), (vx, vy, wi), want):
+        assert np.array_equal(g, w), "staged, %d ranks %s L%d %s: max-abs %.3e" % (nranks, res, levels, name, np.abs(g - w).max())
+    assert n_ex > 0
+
+
+def test_exact_split_over_the_rccl_transport_with_one_rank(gpu):
+    """The RCCL transport itself with sor_mode = 0 (a group of one: no cut, no sends -- the plumbing and the dispatch)."""
+    from papteam_opticalflow_amd import capi
+    a, b = cases.load_pair("240")
+    P = _params()
+    tr = capi.TileRank.create(gpu, capi.tiles_unique_id(), 0, 1)
+    h, w, c = a.shape
+    d1, d2 = gpu.dev_alloc(a.nbytes), gpu.dev_alloc(b.nbytes)
+    dx, dy, dw = gpu.dev_alloc(h * w * 8), gpu.dev_alloc(h * w * 8), gpu.dev_alloc(a.nbytes)
+    gpu.dev_upload(d1, a)
+    gpu.dev_upload(d2, b)
+    tr.flow_device(d1, d2, h, w, c, 3, P, dx, dy, dw)
+    vx, wi = np.zeros((h, w)), np.zeros((h, w, c))
+    gpu.dev_download(vx, dx)
+    gpu.dev_download(wi, dw)
+    tr.close()
+    for p_ in (d1, d2, dx, dy, dw):
+        gpu.dev_free(p_)
+    want = gpu.coarse2fine_flow(a, b, 3, P)
+    assert np.array_equal(vx, want[0]) and np.array_equal(wi, want[2])
+
+
 def test_band_split_rejects_what_it_does_not_cover(gpu):
     from papteam_opticalflow_amd import PapofError
     a, b = cases.load_pair("240")

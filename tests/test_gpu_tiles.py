@@ -178,3 +178,6 @@ def test_bench_tiles_reporting_path_single_rank():
     assert t["n_ranks_seen"] == 1 and t["ranks_seen"] == [0] and t["tile_grid_in_use"] == "1x1"
     assert len(t["sor_ms_per_pair_by_rank"]) == 1 and t["sor_ms_per_pair_by_rank"][0] > 0
     assert r["scaling"] == "weak" and t["scaling"] == "strong" and r["value"] > 0
+    ex = t["exact_order"]  # the same pair in the reference's sweep order, split over the ranks (bands_flow)
+    assert "error" not in ex, ex
+    assert ex["bit_identical_to_one_gpu_exact"] is True and ex["value"] > 0 and ex["n_ranks_seen"] == 1
