@@ -169,10 +169,11 @@ int papof_seq_push_device(papof_handle* h, const void* d_frame, int is_u8, int h
  * tiled 2x4 across 8 GPUs with RCCL halo exchange over xGMI).  One rank per GPU / process; every rank holds both
  * frames; rank 0 receives the assembled (vx, vy, warpI2).  Red-black SOR order (PAPOF_SOR_REDBLACK, n_inner = 1): a
  * red-black half-sweep reads only the other colour's previous values, so the tiled result is bit-identical to
- * papof_flow_device() in that mode on one GPU.  `halo` = ghost-zone depth in half-sweeps (one (du, dv) exchange per
+ * papof_flow_device() in that mode on one GPU.  (PAPOF_SOR_EXACT: see papof_bands_plan below.)  `halo` = ghost-zone depth in half-sweeps (one (du, dv) exchange per
  * `halo` half-sweeps; 0 = default 10).  All calls below except _grid/_rect/_halo_message are collective. */
 typedef struct papof_tiles papof_tiles;
 #define PAPOF_TILES_ID_BYTES 128
+#define PAPOF_BAND_ROWS 62 /* rows per solver band of the exact-order kernel (sor.hip) */
 /* rows x cols grid for n ranks (8 -> 2 x 4: tiles of 480 x 540 at 1080p, 4 -> 2 x 2, 2 -> 1 x 2) */
 int papof_tiles_grid(int nranks, int* rows, int* cols);
 /* rect = {x0, y0, x1, y1} (half-open) of rank's tile of a width x height plane */
@@ -180,6 +181,15 @@ int papof_tiles_rect(int width, int height, int rows, int cols, int rank, int re
 /* the rectangle rank `src` sends to rank `dst` when every rank needs its tile grown by `halo` pixels (empty: x1 <= x0);
  * pure function of its arguments -- both ends of a message compute it, nothing is negotiated */
 int papof_tiles_halo_message(int width, int height, int rows, int cols, int halo, int src, int dst, int rect[4]);
+/* PAPOF_SOR_EXACT on a tile group: the reference's own sweep order, split into `nranks` horizontal ranges of SOLVER BANDS
+ * (csrc/tiles.hip: bands_flow; the rows x cols grid is ignored) -- bit-identical to papof_flow_device(), i.e. the sharded
+ * configuration that meets the 1e-4 parity bar; default branches, n_inner = 1, at most 128 sweeps.  Every rank runs the
+ * bands [B0, B1) of every solve; the one 16-byte cell per step that crosses a cut goes, with the producer's progress, straight
+ * into the planes of the rank below (LOCAL transport: one process, one device), or -- transports that cannot address peer
+ * memory from a kernel: RCCL -- as one message per solve and cut after the producer's kernel has finished (the ranks then take
+ * turns within a solve).  papof_bands_plan: for a height x width level with n_sor sweeps, out = {B0, B1, first / one-past-last
+ * coefficient row the rank's tasks touch, first / one-past-last row whose final increments it holds (a partition)}. */
+int papof_bands_plan(int height, int width, int n_sor, int nranks, int rank, int out[6]);
 /* RCCL transport: rank 0 obtains an id (ncclGetUniqueId) and hands it to every rank by whatever means the launcher
  * has (bench.py: torch.distributed broadcast); then every rank creates its member of the group on its own handle. */
 int papof_tiles_unique_id(unsigned char id[PAPOF_TILES_ID_BYTES]);

@@ -50,7 +50,7 @@ SYMBOLS = [
     "papof_flow_dequantize16", "papof_flow_to_bgr", "papof_set_graph_mode", "papof_sor_plan", "papof_last_sor_stats", "papof_strip_plan", "papof_test_sor_strips",
     "papof_pyramid_levels_for_min_width", "papof_stage_smoothflow_ex", "papof_stage_est_gaussian_mixture",
     "papof_stage_bicubic_warp_ex", "papof_tiles_comm_info", "papof_host_alloc", "papof_host_free",
-    "papof_last_sor_solves",
+    "papof_last_sor_solves", "papof_bands_plan",
 ]
 
 
@@ -96,6 +96,7 @@ def load():
     L.papof_tiles_grid.argtypes = [c_int, _I, _I]
     L.papof_tiles_rect.argtypes = [c_int, c_int, c_int, c_int, c_int, _I]
     L.papof_tiles_halo_message.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _I]
+    L.papof_bands_plan.argtypes = [c_int, c_int, c_int, c_int, c_int, _I]
     L.papof_tiles_unique_id.argtypes = [ctypes.c_char_p]
     L.papof_tiles_create.argtypes = [c_void_p, ctypes.c_char_p, c_int, c_int, c_int, c_int, c_int,
                                      ctypes.POINTER(c_void_p)]
@@ -618,6 +619,13 @@ def tiles_halo_message(width, height, rows, cols, halo, src, dst):
     out = (c_int * 4)()
     _chk(load().papof_tiles_halo_message(width, height, rows, cols, halo, src, dst, out), "papof_tiles_halo_message")
     return tuple(out)
+
+
+def bands_plan(height, width, n_sor, nranks, rank):
+    """exact-order band split of one level: dict(B0, B1, coef_rows, final_rows) of `rank` (include/papof.h)"""
+    out = (c_int * 6)()
+    _chk(load().papof_bands_plan(height, width, n_sor, nranks, rank, out), "papof_bands_plan")
+    return {"B0": out[0], "B1": out[1], "coef_rows": (out[2], out[3]), "final_rows": (out[4], out[5])}
 
 
 def tiles_unique_id():

@@ -1084,6 +1084,16 @@ int papof_tiles_halo_message(int width, int height, int rows, int cols, int halo
     return PAPOF_OK;
 }
 
+int papof_bands_plan(int height, int width, int n_sor, int nranks, int rank, int out[6]) {
+    if (height < 1 || width < 1 || n_sor < 1 || nranks < 1 || rank < 0 || rank >= nranks || !out) return PAPOF_EINVAL;
+    const BandSplit bs{nranks, skew_dims(height, width, n_sor, 1, 1).nb, n_sor, height};
+    out[0] = bs.B(rank);
+    out[1] = bs.B(rank + 1);
+    bs.coef_rows(rank, out[2], out[3]);
+    bs.final_rows(rank, out[4], out[5]);
+    return PAPOF_OK;
+}
+
 int papof_tiles_unique_id(unsigned char id[PAPOF_TILES_ID_BYTES]) {
     if (!id) return PAPOF_EINVAL;
     const RcclApi* api = rccl();
