@@ -386,7 +386,8 @@ def main():
                 traffic = None
         # per level and per kernel: the solver kernels' own HIP-event time of every solve, as the library recorded it
         KIND = {0: "k_sor_exact", 1: "k_sor_fused", 2: "k_sor_group", 3: "k_sor_blocked<redblack>",
-                4: "k_sor_blocked<jacobi>", 5: "k_sor_redblack/k_sor_jacobi (one launch per half-sweep)"}
+                4: "k_sor_blocked<jacobi>", 5: "k_sor_redblack/k_sor_jacobi (one launch per half-sweep)",
+                6: "k_sor_tiny (whole plane in one workgroup)"}
         by_level, by_kernel = [], {}
         for (lh, lw, ns, kind, depth), (n_solves, n_launch, sec) in sorted(solve_log.items(), key=lambda kv: -kv[0][0] * kv[0][1]):
             if sec <= 0 or n_launch <= 0:

@@ -329,7 +329,7 @@ int papof_last_sor_stats(papof_handle* h, int* launches, double* strip_streams_s
 /* Measurement aid for bench.py (roofline.by_level / by_kernel): the solves of the LAST papof_flow* / papof_seq_push* call on
  * this handle, in stream order.  *n = their number; for i < min(*n, cap): info[6 i ..] = {height, width, sweeps, kind,
  * depth, launches} with kind 0 = k_sor_exact, 1 = k_sor_fused, 2 = k_sor_group, 3 / 4 = k_sor_blocked red-black / Jacobi,
- * 5 = one launch per (half-)sweep; depth = software-pipeline depth R (exact order) or (half-)sweeps per launch (blocked);
+ * 5 = one launch per (half-)sweep, 6 = k_sor_tiny (exact order, whole plane in one workgroup); depth = software-pipeline depth R (exact order) or (half-)sweeps per launch (blocked);
  * sec[i] = the solver kernels' own HIP-event seconds of that solve (0 when the call collected no timers). */
 int papof_last_sor_solves(papof_handle* h, int cap, int* n, int* info, double* sec);
 

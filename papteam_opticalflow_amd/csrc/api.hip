@@ -209,6 +209,7 @@ int build_pyramid(papof_handle* h, const std::vector<Level>& L, const std::vecto
 struct SolveBuffers {
     double *im1s, *tmp, *blend, *imdt, *phi;
     SorPlanes sp;
+    SorPlanes sp_tiny{};  // exact order: row-major operands of the levels small enough for k_sor_tiny (sor.hip), else unused
     // the reference's non-default branches (unreachable from its Python entry point; papof_params::interpolation /
     // noise_model): derivative planes of the frame-2 features for in-loop bicubic warping (src/OpticalFlow.cpp:517-521),
     // and the Gaussian-mixture parameters + reduction scratch (:359-367, :539-591)
@@ -224,6 +225,7 @@ int alloc_solve_buffers(Arena& A, int H, int W, int fc, int mode, int n_sor_cap,
     B.imdt = A.f64(np * fc);
     B.phi = A.f64(np);
     PAPOF_TRY(sor_alloc_planes(A, H, W, mode, n_sor_cap, B.sp));
+    if (mode == PAPOF_SOR_EXACT) PAPOF_TRY(sor_alloc_tiny_planes(A, kTinyMaxCells, B.sp_tiny));
     return A.overflow ? PAPOF_ENOMEM : PAPOF_OK;
 }
 
@@ -277,6 +279,9 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
     // out_u / out_v: where the LAST update writes the flow instead of the other pair of planes (the caller's result buffers)
     const Taps g = smooth5_taps();
     int solve_idx = 0;
+    // exact order on a plane small enough to be solved inside one workgroup: row-major operands + k_sor_tiny (sor.hip)
+    const bool tiny = mode == PAPOF_SOR_EXACT && B.sp_tiny.phi && (size_t)H * W <= kTinyMaxCells && sor_tiny_fits(h, H, W, n_sor);
+    SorPlanes& SP = tiny ? B.sp_tiny : B.sp;
     const double* im1s = im1s_ready;  // smoothed frame 1: constant within the level (prepared ahead by flow_device)
     if (!im1s) {
         clk.phase(PAPOF_T_PHASE1_GENERATE);
@@ -292,7 +297,7 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
         // inner fixed-point iterations (src/OpticalFlow.cpp:290-506): after the first one, phi is taken at u + du and
         // psi at imdt + imdx*du + imdy*dv with the increment of the previous solve; the solve itself restarts at 0
         for (int hh = 0; hh < n_inner; hh++) {
-            const SorPlanes* prev = hh == 0 ? nullptr : &B.sp;
+            const SorPlanes* prev = hh == 0 ? nullptr : &SP;
             // phi (Phase2): of the level's initial flow, and inside further inner iterations (at u + du), by its own kernel;
             // for every later outer iteration the previous iteration's update kernel has written it already
             if (count == 0 || hh > 0) {
@@ -302,7 +307,7 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
             // psi (Phase3, src/OpticalFlow.cpp:377-406) and the linear system (Phase4, :414-448) are ONE kernel here: its
             // time is recorded under Phase4 and apportioned between the two timers when they are collected (kPsiShare)
             clk.phase(PAPOF_T_PHASE4_LINEARSYSTEM);
-            PAPOF_TRY(assemble_system(h, B.blend, B.imdt, B.phi, u, v, H, W, fc, alpha, omega, B.sp, nullptr, nullptr,
+            PAPOF_TRY(assemble_system(h, B.blend, B.imdt, B.phi, u, v, H, W, fc, alpha, omega, SP, nullptr, nullptr,
                                       prev, nullptr, B.gm));
             // Phase5_SOR is the solver kernels' own duration (the roofline of the dominant kernel is priced on it): the
             // events are recorded by sor_solve() right around its kernel(s), BEHIND the memset nodes that prepare a solve,
@@ -313,7 +318,7 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
             h->sor_mark_ctx = &clk;
             h->sor_prog_next = prog ? prog + (size_t)solve_idx * prog_per_solve : nullptr;
             solve_idx++;
-            const int rc_solve = sor_solve(h, B.sp, H, W, alpha, omega, n_sor, mode);
+            const int rc_solve = sor_solve(h, SP, H, W, alpha, omega, n_sor, mode);
             h->sor_prog_next = nullptr;
             h->sor_mark = nullptr;
             h->sor_mark_ctx = nullptr;
@@ -325,11 +330,11 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
         // next level warps anew, the result is the bicubic warp of the originals): final_warp = false skips it
         const bool rewarp = !fold_warp && !B.bgx && (final_warp || count + 1 < n_outer || B.gm);
         if (out_u && out_v && count + 1 == n_outer) {  // the level's result goes straight to the caller's buffers
-            PAPOF_TRY(update_warp_phi(h, B.sp, u, v, out_u, out_v, f1, f2, warp, phi_next, H, W, fc, rewarp));
+            PAPOF_TRY(update_warp_phi(h, SP, u, v, out_u, out_v, f1, f2, warp, phi_next, H, W, fc, rewarp));
             u = out_u;
             v = out_v;
         } else {
-            PAPOF_TRY(update_warp_phi(h, B.sp, u, v, ua, va, f1, f2, warp, phi_next, H, W, fc, rewarp));
+            PAPOF_TRY(update_warp_phi(h, SP, u, v, ua, va, f1, f2, warp, phi_next, H, W, fc, rewarp));
             std::swap(u, ua);
             std::swap(v, va);
         }
@@ -955,7 +960,8 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
             const int n_sor_k = P.n_sor + k * P.n_sor_per_level, n_outer_k = P.n_outer + k * P.n_outer_per_level;
             unsigned* prog_k = nullptr;
             if (exact) prog_k = h->sync_words + 32 + LP[k].prog_off;  // this level's counters, cleared by the preparation stream
-            PAPOF_TRY(sor_bind(h, B.sp, lh, lw, n_sor_k));
+            const bool tiny_k = exact && (size_t)lw * lh <= kTinyMaxCells && sor_tiny_fits(h, lh, lw, n_sor_k);  // k_sor_tiny level
+            if (!tiny_k) PAPOF_TRY(sor_bind(h, B.sp, lh, lw, n_sor_k));
             // the level's result goes straight to the caller's buffers on the finest level
             double* const out_u = k == 0 ? d_vx : nullptr;
             double* const out_v = k == 0 ? d_vy : nullptr;
@@ -964,7 +970,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
             // OFF by default (PAPOF_STRIPS=2..4 enables): measured slower on every level it applies to
             const int want = h->strips > 1 ? h->strips : 1;
             const bool strips = overlap && (int)h->strip_streams.size() >= 3 && P.sor_mode == PAPOF_SOR_EXACT &&
-                                P.n_inner == 1 && !B.bgx && !B.gm && want >= 2 &&
+                                P.n_inner == 1 && !B.bgx && !B.gm && want >= 2 && !tiny_k &&
                                 plan_strips(h, B.sp, lh, n_sor_k, n_outer_k, want, sch);
             LevelInit li{k == levels - 1, nullptr, nullptr, ph, pw, 0.0, 0.0, 1 / ratio};
             const bool fold_warp = !strips && !B.bgx && !B.gm;  // the warped frame 2 lives only inside the smoothing kernel
@@ -995,7 +1001,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
                     PAPOF_TRY(bicubic_warp(h, f1, f2, B.bgx, B.bgy, B.bgxy, u, v, warp, lh, lw, fc, nullptr, true, false));
                 }
             }
-            PAPOF_TRY(sor_reset_planes(h, B.sp));
+            if (!tiny_k) PAPOF_TRY(sor_reset_planes(h, B.sp));
             if (strips)
                 PAPOF_TRY(smooth_flow_strips(h, sch, li, f1, f2, warp, u, v, u2, v2, lh, lw, fc, P.alpha, n_sor_k, P.omega, B,
                                              clk, uclk, S1[k], prog_k, LP[k].prog_per, out_u, out_v));
@@ -1894,6 +1900,11 @@ int papof_stage_laplacian(papof_handle* h, const double* in, const double* weigh
 
 namespace {
 int alloc_sor_planes(Scope& S, int H, int W, int mode, int n_sor, SorPlanes& sp) {
+    if (mode == PAPOF_SOR_EXACT && (size_t)H * W <= kTinyMaxCells && sor_tiny_fits(S.h, H, W, n_sor)) {  // k_sor_tiny
+        const int rc_t = sor_alloc_tiny_planes(S.h->arena, (size_t)H * W, sp);
+        if (rc_t != PAPOF_OK) S.rc = rc_t;
+        return S.rc;
+    }
     int rc = sor_alloc_planes(S.h->arena, H, W, mode, n_sor, sp);
     if (rc == PAPOF_OK) rc = sor_bind(S.h, sp, H, W, n_sor);
     if (rc != PAPOF_OK) S.rc = rc;

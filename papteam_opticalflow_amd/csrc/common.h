@@ -396,7 +396,10 @@ struct SorSplit {
 };
 int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor,
                     unsigned* prog, int b0, int b1, const SorSplit* split = nullptr);
-int sor_bind_plain(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor);  // as sor_bind, one sweep per wave / workgroup
+int sor_bind_plain(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor);
+bool sor_tiny_fits(const papof_handle* h, int H, int W, int n_sor);
+constexpr size_t kTinyMaxCells = 8192;  // upper bound of what sor_tiny_fits() accepts (registers of one workgroup)
+int sor_alloc_tiny_planes(Arena& A, size_t cells, SorPlanes& sp);  // exact order inside one workgroup (k_sor_tiny; row-major operands)  // as sor_bind, one sweep per wave / workgroup
 // progress counters cleared ahead of the solves that use them (flow_device: all of a call's, on the preparation stream)
 size_t sor_counters_words(int H, int W, int n_sor);
 int sor_counters_ensure(papof_handle* h, size_t words);

@@ -1627,6 +1627,129 @@ __global__ __launch_bounds__(NW * 64) void k_sor_blocked(BlockedArgs A) {
     });
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// TINY PLANES, exact order: the whole solve inside ONE workgroup (k_sor_tiny).
+//
+// Deep pyramids end in levels of a few thousand cells (the reference's own test matrix runs 15 levels: 1920x1080 goes
+// down to 34x19, with 60-72 sweeps and 17-21 outer iterations there: src/OpticalFlow.cpp:823, Code/Serial/TestSuite.py:91).
+// On such a plane the task pipeline above is nothing but its chain of hand-offs -- every solve costs ~(sweeps x 3.4 us),
+// 170-290 us whatever the size -- so those levels dominated the call.  Here the plane never leaves the CU:
+//   * a TILE is C consecutive cells of one row; tile (row r, segment q) of sweep k runs at tile-time T = r + q + 2k: its
+//     left and upper neighbours (sweep k) ran at T - 1, its right and lower neighbours (sweep k - 1) at T - 1 as well, its
+//     own previous sweep at T - 2 -- the hyperplane schedule of the file header on tiles, so the results are those of the
+//     in-place lexicographic sweeps (src/OpticalFlow.cpp:458-505) exactly; tiles that share a T never touch each other's
+//     cells (r + q has one parity per T);
+//   * a lane owns TWO neighbouring tiles of a row, one of each parity -- it works in every tile-time -- and keeps their
+//     coefficients in REGISTERS for the whole solve (per cell phi, imdxy, the hoisted diagonals, the right-hand sides, and
+//     the weight of the cell above; 14 C + 2 doubles per lane), loaded once with plain row loads;
+//   * the unknowns live in LDS, one 16-byte (du, dv) cell each, in place, framed by a ring of (0, 0) cells: a neighbour that
+//     does not exist contributes w * 0 -- the reference's conditional terms as +-0 added in the same order, as in the
+//     kernels above; a tile reads its 3 C + 2 neighbour cells, updates its C cells left to right (left-new in registers)
+//     and writes them back; ONE workgroup barrier per tile-time orders everything -- no counters, no polling, no
+//     inter-workgroup visibility to argue about;
+//   * R + Q + 2 K - 2 tile-times, each bound by the vector issue of the one CU (~40 instructions per cell and wave).  Measured
+//     (MI355X, inside a 15-level call): 34x19 x 72 sweeps 60 us instead of 287, 60x33 x 66 sweeps 98 instead of 263, 108x60 x
+//     60 sweeps 219 instead of 249; a 240x135 pair on 15 levels 51.5 -> 18.9 ms.
+// Capacity: registers (7 doubles per cell) -- ~7 k cells in a workgroup of 4 waves x 512 registers.  Operands are the
+// ROW-MAJOR planes the red-black / Jacobi modes use (k_assemble writes them, k_update_warp_phi<false> reads the result).
+// ------------------------------------------------------------------------------------------------
+struct TinyArgs {
+    const double *phi, *xy, *a1, *a2, *b1, *b2;
+    double *du, *dv;
+    int H, W, K;
+    int Q, QP;  // segments per row, lanes per row = ceil(Q / 2)
+    double nalpha, om1;
+};
+
+template <int C, int NW>
+__global__ __launch_bounds__(NW * 64) void k_sor_tiny(TinyArgs A) {
+    extern __shared__ f64x2 tiny_lds[];  // (H + 2) x LW cells, row 0 / row H + 1 / column 0 / columns > W: the zero frame
+    const int H = A.H, W = A.W, LW = A.Q * C + 2;
+    const int g = threadIdx.x, nthreads = NW * 64;
+    for (int c = g; c < (H + 2) * LW; c += nthreads) tiny_lds[c] = f64x2{0.0, 0.0};  // du = dv = 0 (:452-453)
+    const int r = g / A.QP, m = g - r * A.QP;
+    const bool lane_on = r < H;
+    // tile 0 of the lane has r + q even, tile 1 odd: at even tile-times every lane works on its tile 0, at odd ones on tile 1
+    const int q0 = 2 * m + (r & 1), q1 = 2 * m + 1 - (r & 1);
+    // ---- coefficients -> registers
+    double cphi[2][C], cxy[2][C], ca1[2][C], ca2[2][C], cb1[2][C], cb2[2][C], cup[2][C], cleft[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int q = t ? q1 : q0, j0 = q * C;
+        const bool tile_on = lane_on && q < A.Q;
+        cleft[t] = (tile_on && j0 > 0 && j0 - 1 < W) ? A.phi[(size_t)r * W + j0 - 1] : 0.0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int j = j0 + c;
+            const bool on = tile_on && j < W;
+            const size_t o = on ? (size_t)r * W + j : 0;
+            cphi[t][c] = on ? A.phi[o] : 0.0;
+            cxy[t][c] = on ? A.xy[o] : 0.0;
+            ca1[t][c] = on ? A.a1[o] : 0.0;
+            ca2[t][c] = on ? A.a2[o] : 0.0;
+            cb1[t][c] = on ? A.b1[o] : 0.0;
+            cb2[t][c] = on ? A.b2[o] : 0.0;
+            cup[t][c] = (on && r > 0) ? A.phi[o - W] : 0.0;
+        }
+    }
+    __syncthreads();
+    const double nalpha = A.nalpha, om1 = A.om1;
+    const int n_t = H + A.Q + 2 * A.K - 2;
+    // one tile: cells j0 .. j0 + C - 1 of row r, left to right
+    const auto tile = [&](auto TT, int T) __attribute__((always_inline)) {
+        constexpr int t = decltype(TT)::value;
+        const int q = t ? q1 : q0;
+        const int d = T - r - q;  // = 2 k
+        const bool on = lane_on && q < A.Q && d >= 0 && (d >> 1) < A.K;
+        if (on) {
+            const int j0 = q * C;
+            f64x2* const row = tiny_lds + (size_t)(r + 1) * LW + (j0 + 1);  // cell (r, j0) in framed coordinates
+            f64x2 left = row[-1];
+            double wl = cleft[t];
+            f64x2 own = row[0];
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const f64x2 right = row[c + 1], up = row[c - LW], down = row[c + LW];
+                const double pc = cphi[t][c];
+                // the terms in the reference's order: left, right, up, down (src/OpticalFlow.cpp:468-495)
+                double s1 = wl * left.x, s2 = wl * left.y;
+                s1 += pc * right.x;
+                s2 += pc * right.y;
+                s1 += cup[t][c] * up.x;
+                s2 += cup[t][c] * up.y;
+                s1 += pc * down.x;
+                s2 += pc * down.y;
+                s1 *= nalpha;
+                s2 *= nalpha;
+                s1 += cxy[t][c] * own.y;
+                const double nu = om1 * own.x + ca1[t][c] * (cb1[t][c] - s1);
+                s2 += cxy[t][c] * nu;
+                const double nv = om1 * own.y + ca2[t][c] * (cb2[t][c] - s2);
+                left = f64x2{nu, nv};
+                wl = pc;
+                own = right;
+                // written at once: nobody reads this cell in this tile-time (tiles that share a T are not neighbours, and the
+                // next cell takes it from `left`).  Columns beyond the plane stay (0, 0): they are somebody's right neighbour
+                if (j0 + c < W) row[c] = left;
+            }
+        }
+    };
+    for (int T = 0; T < n_t; T++) {
+        if (T & 1)
+            tile(std::integral_constant<int, 1>{}, T);
+        else
+            tile(std::integral_constant<int, 0>{}, T);
+        __syncthreads();
+    }
+    for (int c = g; c < H * W; c += nthreads) {
+        const int i = c / W, j = c - i * W;
+        const f64x2 v = tiny_lds[(size_t)(i + 1) * LW + (j + 1)];
+        A.du[c] = v.x;
+        A.dv[c] = v.y;
+    }
+}
+
 }  // namespace
 
 // One colour of a red-black sweep on a region of the (row-major) operand planes.  The whole plane on one GPU; a tile
@@ -1762,6 +1885,96 @@ int sor_blocked_launch(papof_handle* h, const SorPlanes& sp, int H, int W, doubl
     return PAPOF_OK;
 }
 
+
+// ---- the tiny-plane solver's host side ------------------------------------------------------------------
+// Shapes: (cells per tile, waves).  Registers bound the tile: 28 C + 4 for the coefficients of a lane's two tiles, beside
+// ~40 of working set, within 128 / 256 / 512 registers at 16 / 8 / 4 waves per workgroup.
+struct TinyShape {
+    int c, nw;
+};
+static bool tiny_shape(int H, int W, int K, TinyShape& best) {
+    static const TinyShape cand[] = {{1, 16}, {2, 16}, {3, 16}, {4, 12}, {4, 8}, {6, 8}, {7, 8}, {8, 4}, {10, 4}, {14, 4}};
+    double best_cost = -1;
+    for (const TinyShape& t : cand) {
+        const int Q = (W + t.c - 1) / t.c, QP = (Q + 1) / 2;
+        if ((long long)H * QP > t.nw * 64) continue;
+        if ((size_t)(H + 2) * (Q * t.c + 2) * 16 > (size_t)150 * 1024) continue;  // LDS: the framed plane of 16-byte cells
+        // tile-times x the cost of one (us).  Measured: the workgroup is bound by the vector issue of its ONE CU -- every wave
+        // issues ~40 instructions per cell, 4 cycles each, the four SIMDs in parallel -- unless the chain of a tile's C
+        // dependent cells is longer (~70 ns per cell + the barrier)
+        const double issue = (double)t.nw * t.c * 40.0 * 4.0 / 4.0 / 2400.0, chain = t.c * 0.07 + 0.12;
+        const double cost = (double)(H + Q + 2 * K) * std::max(issue, chain);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = t;
+        }
+    }
+    return best_cost >= 0;
+}
+
+// May a height x width plane be solved in exact order by k_sor_tiny?  (PAPOF_SOR_TINY=0 switches the path off: A/B)
+bool sor_tiny_fits(const papof_handle* h, int H, int W, int n_sor) {
+    static const bool off = std::getenv("PAPOF_SOR_TINY") && std::atoi(std::getenv("PAPOF_SOR_TINY")) == 0;
+    (void)h;
+    TinyShape t;
+    return !off && H >= 1 && W >= 1 && n_sor >= 1 && tiny_shape(H, W, n_sor, t);
+}
+
+static int sor_tiny_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor) {
+    TinyShape t;
+    if (sp.skew || !tiny_shape(H, W, n_sor, t)) return PAPOF_EINVAL;
+    TinyArgs A;
+    A.phi = sp.phi;
+    A.xy = sp.xy;
+    A.a1 = sp.a1;
+    A.a2 = sp.a2;
+    A.b1 = sp.b1;
+    A.b2 = sp.b2;
+    A.du = sp.du;
+    A.dv = sp.dv;
+    A.H = H;
+    A.W = W;
+    A.K = n_sor;
+    A.Q = (W + t.c - 1) / t.c;
+    A.QP = (A.Q + 1) / 2;
+    A.nalpha = -alpha;
+    A.om1 = 1 - omega;
+    const size_t lds = (size_t)(H + 2) * (A.Q * t.c + 2) * 16;
+#define PAPOF_TINY(CC, NWW)                                                                                           \
+    do {                                                                                                              \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            PAPOF_HIP(hipFuncSetAttribute((const void*)k_sor_tiny<CC, NWW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          150 * 1024));                                                               \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        hipLaunchKernelGGL((k_sor_tiny<CC, NWW>), dim3(1), dim3(NWW * 64), lds, h->stream, A);                        \
+    } while (0)
+    if (t.c == 1)
+        PAPOF_TINY(1, 16);
+    else if (t.c == 2)
+        PAPOF_TINY(2, 16);
+    else if (t.c == 3)
+        PAPOF_TINY(3, 16);
+    else if (t.c == 4 && t.nw == 12)
+        PAPOF_TINY(4, 12);
+    else if (t.c == 4)
+        PAPOF_TINY(4, 8);
+    else if (t.c == 6)
+        PAPOF_TINY(6, 8);
+    else if (t.c == 7)
+        PAPOF_TINY(7, 8);
+    else if (t.c == 8)
+        PAPOF_TINY(8, 4);
+    else if (t.c == 10)
+        PAPOF_TINY(10, 4);
+    else
+        PAPOF_TINY(14, 4);
+#undef PAPOF_TINY
+    PAPOF_HIP(hipGetLastError());
+    return PAPOF_OK;
+}
+
 // `units` half-sweeps (Jacobi: sweeps) from zero on the whole plane: ceil(units / depth) launches of nearly equal depth,
 // alternating between the two pairs of planes so that the LAST one writes (sp.du, sp.dv).
 int sor_group_size(const papof_handle* h, int H, int W, int n_sor);
@@ -1844,8 +2057,14 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
     const auto log_solve = [&](int kind, int depth, int launches) {
         h->sor_log.push_back(papof_handle::SorSolveLog{H, W, n_sor, kind, depth, launches, 0.0});
     };
+    if (mode == PAPOF_SOR_EXACT && !sp.skew) {  // row-major operands: the plane is solved inside one workgroup (k_sor_tiny)
+        mark(1);
+        PAPOF_TRY(sor_tiny_solve(h, sp, H, W, alpha, omega, n_sor));
+        mark(0);
+        log_solve(6, 0, 1);
+        return PAPOF_OK;
+    }
     if (mode == PAPOF_SOR_EXACT) {
-        if (!sp.skew) return PAPOF_EINVAL;
         const SkewDims sd = skew_dims(H, W, n_sor, sp.sd.group, sp.sd.fuse);
         if (sd.fuse != sp.sd.fuse || sd.hp != sp.sd.hp || sd.npos != sp.sd.npos || sd.qt != sp.sd.qt || sd.nb != sp.sd.nb ||
             sd.n_sor != sp.sd.n_sor || sd.n > sp.cap_cells || sd.nd + sd.nh > sp.cap_cells_d)
@@ -2322,6 +2541,21 @@ int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes&
         sp.du2 = A.f64(n);  // second pair of unknown planes: the blocked solver / Jacobi alternate between the two
         sp.dv2 = A.f64(n);
     }
+    return A.overflow ? PAPOF_ENOMEM : PAPOF_OK;
+}
+
+// Row-major operand planes for the tiny-plane exact-order solver (k_sor_tiny), `cells` doubles each
+int sor_alloc_tiny_planes(Arena& A, size_t cells, SorPlanes& sp) {
+    sp = SorPlanes{};
+    sp.skew = false;
+    sp.phi = A.f64(cells);
+    sp.xy = A.f64(cells);
+    sp.a1 = A.f64(cells);
+    sp.a2 = A.f64(cells);
+    sp.b1 = A.f64(cells);
+    sp.b2 = A.f64(cells);
+    sp.du = A.f64(cells);
+    sp.dv = A.f64(cells);
     return A.overflow ? PAPOF_ENOMEM : PAPOF_OK;
 }
 
