@@ -1651,7 +1651,8 @@ __global__ __launch_bounds__(NW * 64) void k_sor_blocked(BlockedArgs A) {
 //   * R + Q + 2 K - 2 tile-times, each bound by the vector issue of the one CU (~40 instructions per cell and wave).  Measured
 //     (MI355X, inside a 15-level call): 34x19 x 72 sweeps 60 us instead of 287, 60x33 x 66 sweeps 98 instead of 263, 108x60 x
 //     60 sweeps 219 instead of 249; a 240x135 pair on 15 levels 51.5 -> 18.9 ms.
-// Capacity: registers (7 doubles per cell) -- ~7 k cells in a workgroup of 4 waves x 512 registers.  Operands are the
+// Capacity: registers (7 doubles per cell) -- ~5 k cells (tiles of at most 10 cells; wider ones are no faster than the task
+// pipeline).  Operands are the
 // ROW-MAJOR planes the red-black / Jacobi modes use (k_assemble writes them, k_update_warp_phi<false> reads the result).
 // ------------------------------------------------------------------------------------------------
 struct TinyArgs {
@@ -1662,13 +1663,17 @@ struct TinyArgs {
     double nalpha, om1;
 };
 
-template <int C, int NW>
+template <int C, int NW>  // NW: the most waves a launch may have (register budget); a launch has as many as its lanes need
 __global__ __launch_bounds__(NW * 64) void k_sor_tiny(TinyArgs A) {
-    extern __shared__ f64x2 tiny_lds[];  // (H + 2) x LW cells, row 0 / row H + 1 / column 0 / columns > W: the zero frame
-    const int H = A.H, W = A.W, LW = A.Q * C + 2;
-    const int g = threadIdx.x, nthreads = NW * 64;
-    for (int c = g; c < (H + 2) * LW; c += nthreads) tiny_lds[c] = f64x2{0.0, 0.0};  // du = dv = 0 (:452-453)
-    const int r = g / A.QP, m = g - r * A.QP;
+    // LDS layout: cell (row r, column j) -> ((r + 1) * 2C + j % 2C) * (QP + 2) + j / 2C + 1: within a row the cells that the
+    // lanes of a row address with the SAME register index (same position in a lane's pair of tiles) are contiguous, so a
+    // wave's 16-byte accesses fall on consecutive cells -- no bank conflicts for any C (row-major cells would be 2C cells
+    // apart: 4-way conflicts at C = 2).  Row 0 / row H + 1 and the lane slots 0 / QP + 1 are the frame of (0, 0) cells.
+    extern __shared__ f64x2 tiny_lds[];
+    const int H = A.H, W = A.W, QP = A.QP, LS = QP + 2, RS = 2 * C * LS;  // cells per position-row, per image row
+    const int g = threadIdx.x, nthreads = blockDim.x;
+    for (int c = g; c < (H + 2) * RS; c += nthreads) tiny_lds[c] = f64x2{0.0, 0.0};  // du = dv = 0 (:452-453)
+    const int r = g / QP, m = g - r * QP;
     const bool lane_on = r < H;
     // tile 0 of the lane has r + q even, tile 1 odd: at even tile-times every lane works on its tile 0, at odd ones on tile 1
     const int q0 = 2 * m + (r & 1), q1 = 2 * m + 1 - (r & 1);
@@ -1703,14 +1708,26 @@ __global__ __launch_bounds__(NW * 64) void k_sor_tiny(TinyArgs A) {
         const int d = T - r - q;  // = 2 k
         const bool on = lane_on && q < A.Q && d >= 0 && (d >> 1) < A.K;
         if (on) {
-            const int j0 = q * C;
-            f64x2* const row = tiny_lds + (size_t)(r + 1) * LW + (j0 + 1);  // cell (r, j0) in framed coordinates
-            f64x2 left = row[-1];
+            const int j0 = q * C, half = q - 2 * m;  // which half of the lane's pair of tiles: positions half * C ..
+            f64x2* const own0 = tiny_lds + (size_t)((r + 1) * 2 * C + half * C) * LS + (m + 1);  // cell (r, j0)
+            // the cell left of the tile / right of it: the neighbouring position of this lane's slot, or -- at the ends of the
+            // pair -- the last / first position of the neighbouring lane's slot (slots 0 and QP + 1: the zero frame)
+            const f64x2* const lcell = half ? own0 - LS : own0 + (2 * C - 1) * LS - 1;
+            const f64x2* const rcell = half ? own0 - C * LS + 1 : own0 + C * LS;
+            f64x2 left = *lcell;
             double wl = cleft[t];
-            f64x2 own = row[0];
+            f64x2 own = own0[0];
+            // the neighbour cells of cell c + 1 are requested BEFORE cell c is computed and written (distinct cells), so their
+            // LDS latency hides behind the arithmetic
+            f64x2 right = C > 1 ? own0[LS] : *rcell, up = own0[-RS], down = own0[RS];
 #pragma unroll
             for (int c = 0; c < C; c++) {
-                const f64x2 right = row[c + 1], up = row[c - LW], down = row[c + LW];
+                f64x2 nright = right, nup = up, ndown = down;
+                if (c + 1 < C) {
+                    nright = c + 2 < C ? own0[(c + 2) * LS] : *rcell;
+                    nup = own0[(c + 1) * LS - RS];
+                    ndown = own0[(c + 1) * LS + RS];
+                }
                 const double pc = cphi[t][c];
                 // the terms in the reference's order: left, right, up, down (src/OpticalFlow.cpp:468-495)
                 double s1 = wl * left.x, s2 = wl * left.y;
@@ -1731,7 +1748,10 @@ __global__ __launch_bounds__(NW * 64) void k_sor_tiny(TinyArgs A) {
                 own = right;
                 // written at once: nobody reads this cell in this tile-time (tiles that share a T are not neighbours, and the
                 // next cell takes it from `left`).  Columns beyond the plane stay (0, 0): they are somebody's right neighbour
-                if (j0 + c < W) row[c] = left;
+                if (j0 + c < W) own0[c * LS] = left;
+                right = nright;
+                up = nup;
+                down = ndown;
             }
         }
     };
@@ -1744,7 +1764,7 @@ __global__ __launch_bounds__(NW * 64) void k_sor_tiny(TinyArgs A) {
     }
     for (int c = g; c < H * W; c += nthreads) {
         const int i = c / W, j = c - i * W;
-        const f64x2 v = tiny_lds[(size_t)(i + 1) * LW + (j + 1)];
+        const f64x2 v = tiny_lds[(size_t)((i + 1) * 2 * C + j % (2 * C)) * LS + j / (2 * C) + 1];
         A.du[c] = v.x;
         A.dv[c] = v.y;
     }
@@ -1890,26 +1910,28 @@ int sor_blocked_launch(papof_handle* h, const SorPlanes& sp, int H, int W, doubl
 // Shapes: (cells per tile, waves).  Registers bound the tile: 28 C + 4 for the coefficients of a lane's two tiles, beside
 // ~40 of working set, within 128 / 256 / 512 registers at 16 / 8 / 4 waves per workgroup.
 struct TinyShape {
-    int c, nw;
+    int c, nw;  // cells per tile; most waves the instantiation may be launched with
+    int waves;  // waves this plane needs: ceil(rows x lanes per row / 64)
 };
 static bool tiny_shape(int H, int W, int K, TinyShape& best) {
-    static const TinyShape cand[] = {{1, 16}, {2, 16}, {3, 16}, {4, 12}, {4, 8}, {6, 8}, {7, 8}, {8, 4}, {10, 4}, {14, 4}};
-    double best_cost = -1;
-    for (const TinyShape& t : cand) {
+    // Narrow tiles on many waves win while the lanes fit (tools/tiny_sweep.py on MI355X, profiles/r03_tiny_sweep.txt: e.g.
+    // 60x33 x 66 sweeps 91 / 97 / 104 / 113 / 124 / 177 us at C = 1 / 2 / 3 / 4 / 6 / 8): the narrowest shape that holds the
+    // plane is taken.  Tiles of 14 cells (the only shape that holds ~6.5 k cells) run as long as the task pipeline does
+    // (108x60 x 60 sweeps: 249 us either way) and are left to it.
+    static const TinyShape cand[] = {{1, 16, 0}, {2, 16, 0}, {3, 12, 0}, {4, 8, 0}, {5, 8, 0}, {6, 8, 0}, {8, 4, 0}, {10, 4, 0}};
+    static const int force_c = std::getenv("PAPOF_TINY_C") ? std::atoi(std::getenv("PAPOF_TINY_C")) : 0;  // A/B: force C where it fits
+    (void)K;
+    bool found = false;
+    for (TinyShape t : cand) {
         const int Q = (W + t.c - 1) / t.c, QP = (Q + 1) / 2;
         if ((long long)H * QP > t.nw * 64) continue;
-        if ((size_t)(H + 2) * (Q * t.c + 2) * 16 > (size_t)150 * 1024) continue;  // LDS: the framed plane of 16-byte cells
-        // tile-times x the cost of one (us).  Measured: the workgroup is bound by the vector issue of its ONE CU -- every wave
-        // issues ~40 instructions per cell, 4 cycles each, the four SIMDs in parallel -- unless the chain of a tile's C
-        // dependent cells is longer (~70 ns per cell + the barrier)
-        const double issue = (double)t.nw * t.c * 40.0 * 4.0 / 4.0 / 2400.0, chain = t.c * 0.07 + 0.12;
-        const double cost = (double)(H + Q + 2 * K) * std::max(issue, chain);
-        if (best_cost < 0 || cost < best_cost) {
-            best_cost = cost;
-            best = t;
-        }
+        if ((size_t)(H + 2) * 2 * t.c * (QP + 2) * 16 > (size_t)150 * 1024) continue;  // LDS: the framed plane of 16-byte cells
+        t.waves = (H * QP + 63) / 64;
+        if (!found || force_c == t.c) best = t;
+        found = true;
+        if (force_c <= 0) break;
     }
-    return best_cost >= 0;
+    return found;
 }
 
 // May a height x width plane be solved in exact order by k_sor_tiny?  (PAPOF_SOR_TINY=0 switches the path off: A/B)
@@ -1939,7 +1961,7 @@ static int sor_tiny_solve(papof_handle* h, const SorPlanes& sp, int H, int W, do
     A.QP = (A.Q + 1) / 2;
     A.nalpha = -alpha;
     A.om1 = 1 - omega;
-    const size_t lds = (size_t)(H + 2) * (A.Q * t.c + 2) * 16;
+    const size_t lds = (size_t)(H + 2) * 2 * t.c * (A.QP + 2) * 16;
 #define PAPOF_TINY(CC, NWW)                                                                                           \
     do {                                                                                                              \
         static bool attr_set = false;                                                                                 \
@@ -1948,28 +1970,24 @@ static int sor_tiny_solve(papof_handle* h, const SorPlanes& sp, int H, int W, do
                                           150 * 1024));                                                               \
             attr_set = true;                                                                                          \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_sor_tiny<CC, NWW>), dim3(1), dim3(NWW * 64), lds, h->stream, A);                        \
+        hipLaunchKernelGGL((k_sor_tiny<CC, NWW>), dim3(1), dim3(t.waves * 64), lds, h->stream, A);                    \
     } while (0)
     if (t.c == 1)
         PAPOF_TINY(1, 16);
     else if (t.c == 2)
         PAPOF_TINY(2, 16);
     else if (t.c == 3)
-        PAPOF_TINY(3, 16);
-    else if (t.c == 4 && t.nw == 12)
-        PAPOF_TINY(4, 12);
+        PAPOF_TINY(3, 12);
     else if (t.c == 4)
         PAPOF_TINY(4, 8);
+    else if (t.c == 5)
+        PAPOF_TINY(5, 8);
     else if (t.c == 6)
         PAPOF_TINY(6, 8);
-    else if (t.c == 7)
-        PAPOF_TINY(7, 8);
     else if (t.c == 8)
         PAPOF_TINY(8, 4);
-    else if (t.c == 10)
-        PAPOF_TINY(10, 4);
     else
-        PAPOF_TINY(14, 4);
+        PAPOF_TINY(10, 4);
 #undef PAPOF_TINY
     PAPOF_HIP(hipGetLastError());
     return PAPOF_OK;
