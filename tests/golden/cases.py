@@ -176,6 +176,30 @@ def stage_smoothflow(lib):
             "tiny_u": u3, "tiny_v": v3}
 
 
+def lapguard_inputs():
+    """5-channel features on which the reference's `LapPara[k] < 1E-20` guard (src/OpticalFlow.cpp:399-400, fed by
+    estLaplacianNoise, :594-639) TRIPS: channels 0, 1, 2, 4 are the same constant in both frames (every |Im1 - warpIm2| is
+    exactly 0 there: no valid sample, LapPara = 0.001), channel 3 is a 1e-9-sized pattern that differs between the frames by
+    ~1e-21 per sample -- so after the first outer iteration LapPara[3] ~ 1e-21 < 1e-20 and the guard skips channel 3's psi
+    from the second iteration on (the value of the first iteration stays in Psi_1st).  With alpha = 1e-20 the data term of
+    that one channel decides the result, so a restatement that zeroes a skipped psi gives other numbers."""
+    rng = np.random.default_rng(21)
+    h, w = 40, 56
+    pat = 1.0 + 0.4 * np.tanh(smooth_field(rng, h, w, 1.0))
+    f1 = np.full((h, w, 5), 0.25)
+    f2 = np.full((h, w, 5), 0.25)
+    f1[..., 3] = 1e-9 * pat
+    f2[..., 3] = f1[..., 3] * (1 + 2.0 ** -40)
+    return np.ascontiguousarray(f1), np.ascontiguousarray(f2), np.zeros((h, w)), 1e-20
+
+
+def stage_lapguard(lib):
+    f1, f2, z, alpha = lapguard_inputs()
+    w1, u1, v1 = lib.smoothflow_sor(f1, f2, f2, z, z, alpha, 3, 1, 5)
+    w2, u2, v2 = lib.smoothflow_sor(f1, f2, f2, z, z, alpha, 2, 2, 4)
+    return {"warp": w1, "u": u1, "v": v1, "inner2_u": u2, "inner2_v": v2}
+
+
 def stage_flow16(lib):
     """The reference's 16-bit flow encoding (OpticalFlow::SaveOpticalFlow / LoadOpticalFlow, src/OpticalFlow.cpp:963-1015):
     clamp at +-200, the truncating conversion, and the way back."""
@@ -260,6 +284,7 @@ CASES = {
     "stage_laplacian": stage_laplacian,
     "stage_smoothflow": stage_smoothflow,
     "stage_flow16": stage_flow16,
+    "stage_lapguard": stage_lapguard,
     "stage_pyramid_minwidth": stage_pyramid_minwidth,
     "stage_branches": stage_branches,
     "bicubic_240_L3": _opts("240", 3, 1, 0),
