@@ -3,7 +3,7 @@
 tag=$1; ctrs=$2; shift 2
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-rocprofv3 --pmc $ctrs -d gpurun_out/${tag} -o run -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > /dev/null 2> gpurun_out/${tag}.err
+rocprofv3 --pmc $ctrs -d gpurun_out/${tag} -o run -- python3 bench.py --no-cpu-baseline --no-collection --steps 3 --warmup 1 "$@" > /dev/null 2> gpurun_out/${tag}.err
 python3 - <<PY
 import sqlite3
 c=sqlite3.connect("gpurun_out/${tag}/run_results.db")
