@@ -2495,8 +2495,14 @@ int sor_reset_planes(papof_handle* h, const SorPlanes& sp) {
 int sor_group_size(const papof_handle* h, int H, int W, int n_sor) {
     if (!h || !h->use_dpp || n_sor < 2) return 1;
     int g = h->sor_group;
-    if (g == 0) g = 1;  // measured: an isolated 240x135 solve gains 17 % (0.25 -> 0.21 ms), but end to
-                        // end nothing at any size (13.6 vs 13.7 ms for a 240x135 pair): stays opt-in
+    if (g == 0) {
+        // measured: an isolated 240x135 solve gains 17 % (0.25 -> 0.21 ms), a 240x135 pair nothing.  Round 3, inside
+        // 15-level calls (profiles/r03_mid_level_kernels.txt): four sweeps per workgroup through LDS win where a solve is
+        // nothing but its chain of sweep hand-offs -- at most 2 bands from 36 sweeps on (135x75 x 36: 154 vs 167 us, 108x60 x 60:
+        // 206 vs 250), 3 bands from 50 sweeps on (144x81 x 57: 237 vs 258, 192x107 x 54: 243 vs 254) -- and lose elsewhere
+        const int nb = skew_dims(H, W, n_sor).nb;
+        g = ((nb <= 2 && n_sor >= 36) || (nb == 3 && n_sor >= 50)) ? 4 : 1;
+    }
     if (g >= 4) return 4;  // LDS (160 KB) holds the rings of up to 4 waves... and 4 waves = one per SIMD
     return g >= 2 ? 2 : 1;
 }
