@@ -2073,6 +2073,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         if (h->sor_mark) h->sor_mark(h->sor_mark_ctx, on);
     };
     const auto log_solve = [&](int kind, int depth, int launches) {
+        if (h->sor_log.size() >= 4096) h->sor_log.clear();  // (stage / micro-benchmark entry points never reset it)
         h->sor_log.push_back(papof_handle::SorSolveLog{H, W, n_sor, kind, depth, launches, 0.0});
     };
     if (mode == PAPOF_SOR_EXACT && !sp.skew) {  // row-major operands: the plane is solved inside one workgroup (k_sor_tiny)
