@@ -703,6 +703,10 @@ __global__ void k_assemble(const double* __restrict__ blend, const double* __res
 // position (anti-diagonal) the 16 threads of a group store 16 neighbouring rows = 256 contiguous bytes per paired
 // plane -- instead of scattered 16-byte cells.
 constexpr int kTileJ = 16;
+#ifndef PAPOF_V_ASMROWS
+#define PAPOF_V_ASMROWS 16  // same-box A/B (round 3, ms per 1080p pair): 62 rows 10.93-10.96, 31: 10.80, 24: 10.91, 16: 10.73-10.83, 12: 10.76-10.78, 8: 10.85-10.87
+#endif
+constexpr int kAsmRows = PAPOF_V_ASMROWS;  // rows of the assembly kernel's tile (its LDS stage bounds the workgroups per CU)
 struct double2s {
     double x, y;
 };
@@ -715,13 +719,13 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
                                                        double2s* __restrict__ pc, double* __restrict__ o_x2,
                                                        double* __restrict__ o_y2, Taps d, Increment I,
                                                        unsigned long long* stamp, int row0, int row1) {
-    __shared__ double stage[6][kBandRows][kTileJ + 1];
+    __shared__ double stage[6][kAsmRows][kTileJ + 1];
     stamp_now(stamp);
     // tiles start at row0 and rows row0 .. row1-1 are written (a strip of the plane; the whole plane otherwise)
-    const int ib = row0 + blockIdx.y * kBandRows, j0 = blockIdx.x * kTileJ, tid = threadIdx.x;
+    const int ib = row0 + blockIdx.y * kAsmRows, j0 = blockIdx.x * kTileJ, tid = threadIdx.x;
     // block-uniform: no cell of this tile is closer than 2 pixels to an image border
-    const bool interior = ib >= 2 && ib + kBandRows + 2 <= H && j0 >= 2 && j0 + kTileJ + 2 <= W;
-    for (int c = tid; c < kBandRows * kTileJ; c += 256) {
+    const bool interior = ib >= 2 && ib + kAsmRows + 2 <= H && j0 >= 2 && j0 + kTileJ + 2 <= W;
+    for (int c = tid; c < kAsmRows * kTileJ; c += 256) {
         const int r = c / kTileJ, jj = c - r * kTileJ;
         const int i = ib + r, j = j0 + jj;
         if (i < row1 && j < W) {
@@ -742,9 +746,9 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
     const int g = tid / kTileJ, jj = tid - g * kTileJ;  // 16 groups of 16 threads; a group walks anti-diagonals
     const int j = j0 + jj;
     if (j >= W) return;
-    for (int pp = g; pp <= kBandRows + kTileJ - 2; pp += 256 / kTileJ) {  // pp = jj + (row in tile)
+    for (int pp = g; pp <= kAsmRows + kTileJ - 2; pp += 256 / kTileJ) {  // pp = jj + (row in tile)
         const int r = pp - jj;
-        if (r < 0 || r >= kBandRows) continue;
+        if (r < 0 || r >= kAsmRows) continue;
         const int i = ib + r;
         if (i >= row1) continue;
         const size_t q = skew_cell(i, j, sk);
@@ -1261,7 +1265,7 @@ int assemble_system(papof_handle* h, const double* blend, const double* imdt, co
     if (r.empty()) return PAPOF_OK;
     if (out.skew) {
         if (rc && (r.x0 != 0 || r.x1 != W)) return PAPOF_EINVAL;  // skew layout: whole rows only (strips of a plane)
-        hipLaunchKernelGGL(k_assemble_skew, dim3((W + kTileJ - 1) / kTileJ, (r.y1 - r.y0 + kBandRows - 1) / kBandRows),
+        hipLaunchKernelGGL(k_assemble_skew, dim3((W + kTileJ - 1) / kTileJ, (r.y1 - r.y0 + kAsmRows - 1) / kAsmRows),
                            dim3(256), 0, h->stream, blend, imdt, phi, u, v, H, W, planes, alpha, omega, skew_idx(out),
                            (double2s*)out.phi, (double2s*)out.a1, (double2s*)out.b1, opt_imdx2, opt_imdy2,
                            deriv5_taps(), I, take_stamp(h), r.y0, r.y1);
