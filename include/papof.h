@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PAPOF_VERSION 103 /* 0.1.3: papof_last_sor_solves, exact-order band split over ranks (papof_tiles_*, PAPOF_SOR_EXACT); 0.1.2: measurement / test aids (papof_last_sor_stats, papof_strip_plan, papof_test_sor_strips); 0.1.1: papof_params gained interpolation / noise_model */
+#define PAPOF_VERSION 104 /* 0.1.4: the Laplacian-noise guard (papof_lap_guard_stats); 0.1.3: papof_last_sor_solves, exact-order band split over ranks (papof_tiles_*, PAPOF_SOR_EXACT); 0.1.2: measurement / test aids (papof_last_sor_stats, papof_strip_plan, papof_test_sor_strips); 0.1.1: papof_params gained interpolation / noise_model */
 
 enum {
     PAPOF_OK = 0,
@@ -332,6 +332,18 @@ int papof_last_sor_stats(papof_handle* h, int* launches, double* strip_streams_s
  * 5 = one launch per (half-)sweep, 6 = k_sor_tiny (exact order, whole plane in one workgroup); depth = software-pipeline depth R (exact order) or (half-)sweeps per launch (blocked);
  * sec[i] = the solver kernels' own HIP-event seconds of that solve (0 when the call collected no timers). */
 int papof_last_sor_solves(papof_handle* h, int cap, int* n, int* info, double* sec);
+
+/* The Laplacian-noise guard of the reference (src/OpticalFlow.cpp:399-400: psi of a feature channel stays 0 while the
+ * channel's noise estimate, estLaplacianNoise :594-639, is below 1E-20 -- duplicate frames, flat synthetic images).  A call
+ * runs WITHOUT the estimate while it collects proofs that the guard could not have tripped (csrc/api.hip: LapGuard); a call
+ * that ends without them is run again inside the same papof_flow* call with the estimate after every outer iteration and
+ * the guard in the assembly, and the handle then stays in that exact pass until a call proves it unnecessary again.  Results
+ * are the reference's either way.  out[0] = calls that were run twice, out[1] = calls run in the exact pass from the start,
+ * out[2] = 1 when the next call will start in the exact pass, out[3] = 0 when PAPOF_LAP_GUARD=0 switched the guard off (an
+ * A/B switch for its cost: results then differ from the reference's on tripping inputs).  hipGraph replay, the bicubic
+ * branch and the papof_stage_smoothflow* entry points always take the exact pass; the Gaussian-mixture branch has no such
+ * guard (:381-397); the multi-rank paths (papof_tiles_*) run without it. */
+int papof_lap_guard_stats(papof_handle* h, int out[4]);
 
 /* Test aid: the strip schedule (api.hip: smooth_flow_strips) a level of height x width with `n_sor` sweeps and
  * `n_outer` outer iterations gets on this handle.  *strips = S (1: the level is not cut).  out, if not NULL, receives

@@ -50,7 +50,7 @@ SYMBOLS = [
     "papof_flow_dequantize16", "papof_flow_to_bgr", "papof_set_graph_mode", "papof_sor_plan", "papof_last_sor_stats", "papof_strip_plan", "papof_test_sor_strips",
     "papof_pyramid_levels_for_min_width", "papof_stage_smoothflow_ex", "papof_stage_est_gaussian_mixture",
     "papof_stage_bicubic_warp_ex", "papof_tiles_comm_info", "papof_host_alloc", "papof_host_free",
-    "papof_last_sor_solves", "papof_bands_plan",
+    "papof_last_sor_solves", "papof_bands_plan", "papof_lap_guard_stats",
 ]
 
 
@@ -141,6 +141,7 @@ def load():
     L.papof_last_sor_stats.argtypes = [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]
     L.papof_last_sor_solves.argtypes = [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                         ctypes.POINTER(ctypes.c_double)]
+    L.papof_lap_guard_stats.argtypes = [c_void_p, ctypes.POINTER(c_int)]
     L.papof_test_sor_strips.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                         ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(c_int)]
     L.papof_strip_plan.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int),
@@ -572,6 +573,12 @@ class Papof:
         _chk(self.L.papof_last_sor_solves(self.h, cap, ctypes.byref(n), info, sec), "papof_last_sor_solves")
         keys = ("h", "w", "n_sor", "kind", "depth", "launches")
         return [dict(zip(keys, info[6 * i:6 * i + 6]), sec=sec[i]) for i in range(min(cap, n.value))]
+
+    def lap_guard_stats(self):
+        """dict(reruns, exact_calls, exact_next, guard_on): the Laplacian-noise guard (include/papof.h: papof_lap_guard_stats)"""
+        out = (c_int * 4)()
+        _chk(self.L.papof_lap_guard_stats(self.h, out), "papof_lap_guard_stats")
+        return dict(reruns=out[0], exact_calls=out[1], exact_next=bool(out[2]), guard_on=bool(out[3]))
 
     def test_sor_strips(self, h, w, n_sor, split_band, reps=3, delay_us=0):
         """(mismatching cells of a solve cut into two strips vs the whole solve, bands of the layout)"""

@@ -262,9 +262,49 @@ int bicubic_planes(papof_handle* h, const double* f2, int H, int W, int fc, Solv
     return PAPOF_OK;
 }
 
+// The Laplacian-noise guard.  After every outer iteration the reference estimates, per channel, the mean of |Im1 - warpIm2|
+// over its samples in (0, 1e6) (estLaplacianNoise, src/OpticalFlow.cpp:594-639; 0.001 when there is none) and, in the next
+// linear system, leaves psi of a channel at 0 while that mean is below 1E-20 (:399-400 on the Psi_1st reset at :333).  No
+// 8-bit frame gets there, and the warped image is never materialised on this path, so the reduction would be a gather pass
+// per iteration for nothing.  Instead a call runs OPTIMISTICALLY -- no guard -- while it collects proofs that the guard
+// could not have tripped: a WITNESS per channel and iteration (one sampled pixel per block of the update kernel with
+// |d| >= 2e-20 x pixels: a sum of positives is at least its largest term), or a channel that is all zero in both frames of the
+// level (no valid sample: LapPara = 0.001).  A call that ends with a channel lacking both is run AGAIN in the EXACT pass --
+// the estimate after every update (kernels.hip: est_laplacian_noise), the guard in the assembly -- and the handle stays in
+// the exact pass while its inputs stay that way (duplicate frames, flat synthetic images).  Results: the reference's, either way
+// (golden `stage_lapguard`); cost on ordinary frames: one sampled warp per block of a kernel that runs anyway.
+struct LapGuard {
+    bool on = false;        // Laplacian noise model, at most 8 feature channels, the handle has its flag block
+    bool exact = false;     // the exact pass
+    bool collect = false;   // witnesses are collected (always, except inside a hipGraph: nobody could act on them)
+    bool nz_known = false;  // the non-zero flags of the feature channels are collected too (im2feature ran for this call)
+    unsigned* flags = nullptr;  // device: papof_handle::lap_flags_dev
+    double* lap = nullptr;      // device: LapPara (exact pass)
+    double* scratch = nullptr;
+    unsigned epoch = 0;  // what a set flag of this pass holds (papof_handle::lap_epoch)
+    int slot = 0;  // outer iterations so far
+    std::vector<int> slot_level, slot_channels;
+    unsigned* wit(int s) const { return on && collect && s >= 0 && s < kLapMaxSlots ? flags + lap_wit_word(s) : nullptr; }
+    unsigned* nz(int level) const { return on && collect && nz_known ? flags + lap_nz_word(level) : nullptr; }
+    const double* guard() const { return on && exact ? lap : nullptr; }
+    // after the stream has drained and the flags are on the host: estimates that were consulted without a proof
+    int unknown(const unsigned* host_flags) const {
+        if (!on || !collect) return 0;
+        if (slot > kLapMaxSlots) return 1;  // more outer iterations than witness slots: take the exact pass
+        int n = 0;
+        for (int s = 0; s + 1 < slot; s++)  // the estimate behind the last iteration of a call is never consulted
+            for (int c = 0; c < slot_channels[s]; c++) {
+                const bool witness = host_flags[lap_wit_word(s) + c] == epoch;
+                const bool all_zero = nz_known && host_flags[lap_nz_word(slot_level[s]) + c] != epoch;
+                n += !(witness || all_zero);
+            }
+        return n;
+    }
+};
+
 // OpticalFlow::SmoothFlowSOR (src/OpticalFlow.cpp:238-536) for one level, everything on the device.
-// genInImageMask (:278) and estLaplacianNoise (:530) do not influence the results (the mask
-// is never read; the noise estimate only feeds a `< 1e-20` guard) and are not executed.
+// genInImageMask (:278) does not influence the results (the mask is never read) and is not executed;
+// estLaplacianNoise (:530) only feeds a `< 1e-20` guard: see LapGuard above.
 // (u, v) and (ua, va) are two pairs of planes: every outer iteration writes the updated flow into the other pair (its
 // update kernel also reads the neighbours' old values, for phi) and the references are swapped -- on return `u`, `v` name
 // the planes that hold the result.
@@ -272,7 +312,7 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
                 double*& va, int H, int W, int fc, double alpha, int n_outer, int n_inner, int n_sor, double omega,
                 int mode, SolveBuffers& B, PhaseClock& clk, const double* im1s_ready = nullptr,
                 bool final_warp = true, unsigned* prog = nullptr, size_t prog_per_solve = 0, double* out_u = nullptr,
-                double* out_v = nullptr, bool fold_warp = false) {
+                double* out_v = nullptr, bool fold_warp = false, LapGuard* lg = nullptr, int level = 0) {
     // fold_warp: nobody but getDxs' smoothing reads the warped frame 2 (default branches, caller = flow_device): it is
     // evaluated inside the smoothing kernel from (u, v) and never written -- `warp` is then neither read nor written here
     // prog: cleared progress counters of this level's solves (solve i: prog + i * prog_per_solve), or null;
@@ -291,7 +331,10 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
     for (int count = 0; count < n_outer; count++) {
         clk.phase(PAPOF_T_PHASE1_GENERATE);
         if (fold_warp)
-            PAPOF_TRY(warp_smooth_blend(h, f1, f2, u, v, im1s, B.blend, B.imdt, H, W, fc));  // warp + both passes + blend + imdt
+            // warp + both passes + blend + imdt; the warp at the flow the previous iteration left is what that iteration's
+            // noise estimate is about: its witnesses are taken here (LapGuard)
+            PAPOF_TRY(warp_smooth_blend(h, f1, f2, u, v, im1s, B.blend, B.imdt, H, W, fc,
+                                        lg && count > 0 && !B.gm ? lg->wit(lg->slot - 1) : nullptr));
         else
             PAPOF_TRY(smooth_hv_blend(h, warp, im1s, B.blend, B.imdt, H, W, fc));  // both passes + blend + imdt, fused
         // inner fixed-point iterations (src/OpticalFlow.cpp:290-506): after the first one, phi is taken at u + du and
@@ -308,7 +351,7 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
             // time is recorded under Phase4 and apportioned between the two timers when they are collected (kPsiShare)
             clk.phase(PAPOF_T_PHASE4_LINEARSYSTEM);
             PAPOF_TRY(assemble_system(h, B.blend, B.imdt, B.phi, u, v, H, W, fc, alpha, omega, SP, nullptr, nullptr,
-                                      prev, nullptr, B.gm));
+                                      prev, nullptr, B.gm, lg ? lg->guard() : nullptr));
             // Phase5_SOR is the solver kernels' own duration (the roofline of the dominant kernel is priced on it): the
             // events are recorded by sor_solve() right around its kernel(s), BEHIND the memset nodes that prepare a solve,
             // which therefore still count as Phase4
@@ -329,17 +372,32 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
         // the re-warp after the LAST outer iteration of a level (:516) is read by nobody when the caller is flow_device (the
         // next level warps anew, the result is the bicubic warp of the originals): final_warp = false skips it
         const bool rewarp = !fold_warp && !B.bgx && (final_warp || count + 1 < n_outer || B.gm);
+        // witnesses of the Laplacian-noise guard (LapGuard); the bicubic branch has no sampled warp: it runs the exact pass
+        // -- and taken by the next iteration's warp_smooth_blend where there is one on this level
+        const bool wit_later = fold_warp && count + 1 < n_outer;
+        unsigned* const wit = lg && !B.gm && !B.bgx && !wit_later ? lg->wit(lg->slot) : nullptr;
         if (out_u && out_v && count + 1 == n_outer) {  // the level's result goes straight to the caller's buffers
-            PAPOF_TRY(update_warp_phi(h, SP, u, v, out_u, out_v, f1, f2, warp, phi_next, H, W, fc, rewarp));
+            PAPOF_TRY(update_warp_phi(h, SP, u, v, out_u, out_v, f1, f2, warp, phi_next, H, W, fc, rewarp, 0, -1, wit));
             u = out_u;
             v = out_v;
         } else {
-            PAPOF_TRY(update_warp_phi(h, SP, u, v, ua, va, f1, f2, warp, phi_next, H, W, fc, rewarp));
+            PAPOF_TRY(update_warp_phi(h, SP, u, v, ua, va, f1, f2, warp, phi_next, H, W, fc, rewarp, 0, -1, wit));
             std::swap(u, ua);
             std::swap(v, va);
         }
         if (B.bgx)  // interpolation == Bicubic: warpImageBicubicRef + threshold() on the feature planes
             PAPOF_TRY(bicubic_warp(h, f1, f2, B.bgx, B.bgy, B.bgxy, u, v, warp, H, W, fc, nullptr, true, true));
+        if (lg && lg->on && !B.gm) {
+            lg->slot_level.push_back(level);
+            lg->slot_channels.push_back(fc);
+            lg->slot++;
+            if (lg->exact) {  // :530, on the flow just updated
+                if (B.bgx)
+                    PAPOF_TRY(est_laplacian_noise(h, f1, warp, nullptr, nullptr, H, W, fc, lg->lap, lg->scratch));
+                else
+                    PAPOF_TRY(est_laplacian_noise(h, f1, f2, u, v, H, W, fc, lg->lap, lg->scratch));
+            }
+        }
         if (B.gm) PAPOF_TRY(est_gaussian_mixture(h, f1, warp, H, W, fc, B.gm, B.gm_scratch));  // :524-528
     }
     clk.phase(-1);
@@ -573,9 +631,9 @@ bool seq_matches(const papof_handle* h, int H, int W, int C, int levels, double 
            q.arena_base == h->arena.base && need <= h->arena.cap;
 }
 
-// The whole call on device-resident buffers.
-int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, int H, int W, int C, int levels,
-                const papof_params& P, double* d_vx, double* d_vy, double* d_warp, double* timing) {
+// The whole call on device-resident buffers: ONE pass (flow_device below runs it once, or twice: LapGuard).
+int flow_pass(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, int H, int W, int C, int levels,
+              const papof_params& P, double* d_vx, double* d_vy, double* d_warp, double* timing, LapGuard* lg) {
     PAPOF_TRY(check_params(P, levels));
     double ratio = P.ratio;
     if (ratio > 0.98 || ratio < 0.4) ratio = 0.75;
@@ -844,8 +902,8 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
                 PAPOF_TRY(build_level(k));
             }
             pclk.phase(PAPOF_T_ALLOCATION);  // im2feature is inside the reference's Allocation timer (:797-798)
-            PAPOF_TRY(im2feature(h, L[k].p1, F1[k], L[k].h, L[k].w, C));
-            PAPOF_TRY(im2feature(h, L[k].p2, F2[k], L[k].h, L[k].w, C));
+            PAPOF_TRY(im2feature(h, L[k].p1, F1[k], L[k].h, L[k].w, C, lg ? lg->nz(k) : nullptr));
+            PAPOF_TRY(im2feature(h, L[k].p2, F2[k], L[k].h, L[k].w, C, lg ? lg->nz(k) : nullptr));
             pclk.phase(PAPOF_T_PHASE1_GENERATE);  // smoothing of frame 1: first half of getDxs (:84-90)
             PAPOF_TRY(filter_hv(h, F1[k], S1[k], prep_tmp, L[k].h, L[k].w, fc, g5, g5));
             pclk.phase(-1);
@@ -893,7 +951,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         }
         for (int k = levels - 1; k >= 0; k--) {
             pclk.phase(PAPOF_T_ALLOCATION);
-            PAPOF_TRY(im2feature(h, L[k].p1, F1[k], L[k].h, L[k].w, C));
+            PAPOF_TRY(im2feature(h, L[k].p1, F1[k], L[k].h, L[k].w, C, lg ? lg->nz(k) : nullptr));
             pclk.phase(PAPOF_T_PHASE1_GENERATE);
             PAPOF_TRY(filter_hv(h, F1[k], S1[k], prep_tmp, L[k].h, L[k].w, fc, g5, g5));
         }
@@ -914,7 +972,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
                 PAPOF_TRY(build_level(k, 1));
             }
             pclk.phase(PAPOF_T_ALLOCATION);
-            PAPOF_TRY(im2feature(h, L[k].p2, F2[k], L[k].h, L[k].w, C));
+            PAPOF_TRY(im2feature(h, L[k].p2, F2[k], L[k].h, L[k].w, C, lg ? lg->nz(k) : nullptr));
             pclk.phase(-1);
             PAPOF_HIP(hipEventRecord(h->sync_events[k], prep));
         }
@@ -950,6 +1008,8 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     int pw = 0, ph = 0;
     int rc_main = PAPOF_OK;
     const auto solve_levels = [&]() -> int {
+        if (lg && lg->guard())  // LapPara starts every call at 0.02 (src/OpticalFlow.cpp:773-775)
+            PAPOF_HIP(hipMemcpyAsync(lg->lap, h->lap_init_dev, 8 * sizeof(double), hipMemcpyDeviceToDevice, main_stream));
         for (int k = levels - 1; k >= 0; k--) {
             const int lw = L[k].w, lh = L[k].h;
             const size_t np = (size_t)lw * lh;
@@ -1008,7 +1068,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
             else
                 PAPOF_TRY(smooth_flow(h, f1, f2, warp, u, v, u2, v2, lh, lw, fc, P.alpha, n_outer_k, P.n_inner, n_sor_k,
                                       P.omega, P.sor_mode, B, clk, S1[k], false, prog_k, exact ? LP[k].prog_per : 0, out_u,
-                                      out_v, fold_warp));
+                                      out_v, fold_warp, lg, k));
             pw = lw;
             ph = lh;
         }
@@ -1066,9 +1126,13 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     PAPOF_TRY(stamp_only(h));  // the closing stamp of the last phase
     total.phase(-1);
     h->stamps_fetched = 0;
-    if (h->stamps_dev && h->stamps_used > 0) {  // behind the total's end event: not part of any timer
-        PAPOF_HIP(hipMemcpyAsync(h->stamps, h->stamps_dev, (size_t)h->stamps_used * sizeof(unsigned long long),
-                                 hipMemcpyDeviceToHost, h->stream));
+    {   // behind the total's end event, not part of any timer: the stamps and, in front of them in the same block, the guard's
+        // flags of this call (the used witness slots end where the non-zero flags begin, those where the stamps begin)
+        const bool flags = lg && lg->on && lg->collect;
+        const size_t first = flags ? lap_wit_word(std::min(lg->slot, kLapMaxSlots) - 1) : kLapFlagWords;
+        const size_t bytes = (kLapFlagWords - first) * sizeof(unsigned) + (size_t)h->stamps_used * sizeof(unsigned long long);
+        if (bytes > 0)
+            PAPOF_HIP(hipMemcpyAsync(h->lap_flags_host + first, h->lap_flags_dev + first, bytes, hipMemcpyDeviceToHost, h->stream));
         h->stamps_fetched = h->stamps_used;
     }
     PAPOF_HIP(hipStreamSynchronize(h->stream));
@@ -1098,6 +1162,55 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     }
     if (timing) std::memcpy(timing, tm, sizeof tm);
     if (op == kSeqNext) keep(slot1 ^ 1);  // the frame just solved against becomes frame 1 of the next push
+    return PAPOF_OK;
+}
+
+// The whole call on device-resident buffers, with the Laplacian-noise guard (LapGuard): the optimistic pass, and the exact
+// pass behind it when a consulted estimate is left without a proof.
+int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, int H, int W, int C, int levels,
+                const papof_params& P, double* d_vx, double* d_vy, double* d_warp, double* timing) {
+    LapGuard lg;
+    const int fc = feature_channels(C);
+    // [strips (PAPOF_STRIPS, off by default, an A/B switch) update the flow per strip and carry no witnesses]
+    lg.on = h->lap_guard && op != kSeqPrime && P.noise_model == PAPOF_NOISE_LAPLACIAN && fc <= 8 && levels >= 1 &&
+            h->lap_flags_dev != nullptr && h->strips <= 1;
+    if (!lg.on) return flow_pass(h, fa, fb, op, H, W, C, levels, P, d_vx, d_vy, d_warp, timing, nullptr);
+    lg.flags = h->lap_flags_dev;
+    lg.lap = h->lap_dev;
+    lg.scratch = h->lap_scratch_dev;
+    lg.nz_known = (size_t)levels * 8 <= (size_t)kLapNzWords;
+    // inside a hipGraph nobody could act on the flags, and the bicubic branch has no sampled warp: always the exact pass
+    const bool always_exact = h->use_graph || P.interpolation == PAPOF_INTERP_BICUBIC;
+    lg.collect = !always_exact;
+    lg.exact = always_exact || h->lap_exact;
+    const papof_handle::Seq seq0 = h->seq;
+    for (int pass = 0; pass < 2; pass++) {
+        // a flag is set when it holds the number of the pass that wrote it: no clearing, nothing stale can be taken for a proof
+        if (++h->lap_epoch == 0u) {  // (2^32 passes later: start over on cleared flags)
+            PAPOF_HIP(hipMemsetAsync(h->lap_flags_dev, 0, kLapFlagWords * sizeof(unsigned), h->stream));
+            h->lap_epoch = 1u;
+        }
+        lg.epoch = h->lap_epoch;
+        lg.slot = 0;
+        lg.slot_level.clear();
+        lg.slot_channels.clear();
+        PAPOF_TRY(flow_pass(h, fa, fb, op, H, W, C, levels, P, d_vx, d_vy, d_warp, timing, &lg));
+        if (!lg.collect) return PAPOF_OK;
+        const int unknown = lg.unknown(h->lap_flags_host);
+        if (lg.exact) {  // the exact pass is right whatever the flags say; they decide how the NEXT call starts
+            if (pass == 0) h->lap_exact_calls++;
+            h->lap_exact = unknown > 0;
+            return PAPOF_OK;
+        }
+        if (unknown == 0) return PAPOF_OK;
+        // ---- a consulted estimate without a proof: the same call again, in the exact pass.  The frames are on the device
+        // already (host uploads of the first pass), the kept pyramid of a sequence is where it was.
+        h->lap_reruns++;
+        lg.exact = true;
+        h->seq = seq0;
+        h->hostio.im1 = nullptr;
+        h->hostio.im2 = nullptr;
+    }
     return PAPOF_OK;
 }
 
@@ -1225,14 +1338,30 @@ int papof_create(int device, papof_handle** out) {
         papof_destroy(h);
         return rc;
     }
-    // slots for the phase stamps (device memory + a pinned host copy fetched once per call)
-    if (hipMalloc((void**)&h->stamps_dev, 4096 * sizeof(unsigned long long)) == hipSuccess &&
-        hipHostMalloc((void**)&h->stamps, 4096 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess) {
-        h->stamps_cap = 4096;
-    } else {  // no stamps: the stamped timers read 0, everything else works
-        if (h->stamps_dev) hipFree(h->stamps_dev);
-        h->stamps_dev = nullptr;
-        h->stamps = nullptr;
+    // flags of the Laplacian-noise guard + slots for the phase stamps: one block of device memory and one pinned host copy,
+    // fetched with ONE copy per call (common.h: lap_flags_dev); LapPara, its initial value and the reduction's scratch
+    {
+        const size_t flag_bytes = kLapFlagWords * sizeof(unsigned), bytes = flag_bytes + 4096 * sizeof(unsigned long long);
+        const size_t lap_doubles = 16 + (size_t)lap_scratch_doubles();
+        std::vector<double> init(8, 0.02);  // src/OpticalFlow.cpp:773-775
+        if (hipMalloc((void**)&h->lap_flags_dev, bytes) == hipSuccess &&
+            hipHostMalloc((void**)&h->lap_flags_host, bytes, hipHostMallocDefault) == hipSuccess &&
+            hipMalloc((void**)&h->lap_dev, lap_doubles * sizeof(double)) == hipSuccess &&
+            hipMemset(h->lap_flags_dev, 0, flag_bytes) == hipSuccess &&
+            hipMemcpy(h->lap_dev + 8, init.data(), 8 * sizeof(double), hipMemcpyHostToDevice) == hipSuccess) {
+            h->stamps_dev = reinterpret_cast<unsigned long long*>(h->lap_flags_dev + kLapFlagWords);
+            h->stamps = reinterpret_cast<unsigned long long*>(h->lap_flags_host + kLapFlagWords);
+            h->stamps_cap = 4096;
+            h->lap_init_dev = h->lap_dev + 8;
+            h->lap_scratch_dev = h->lap_dev + 16;
+            std::memset(h->lap_flags_host, 0, bytes);
+        } else {  // the guard cannot be left out: its absence would change results on some inputs
+            g_last_error = "cannot allocate the flag / stamp block of the handle";
+            papof_destroy(h);
+            return PAPOF_ENOMEM;
+        }
+        const char* lgv = std::getenv("PAPOF_LAP_GUARD");
+        h->lap_guard = !(lgv && lgv[0] == '0');
     }
     *out = h;
     return PAPOF_OK;
@@ -1262,8 +1391,9 @@ void papof_destroy(papof_handle* h) {
     if (h->sync_words) hipFree(h->sync_words);
     if (h->stage_dev) hipFree(h->stage_dev);
     if (h->pin) hipHostFree(h->pin);
-    if (h->stamps) hipHostFree(h->stamps);
-    if (h->stamps_dev) hipFree(h->stamps_dev);
+    if (h->lap_flags_host) hipHostFree(h->lap_flags_host);  // the stamps live inside these two blocks
+    if (h->lap_flags_dev) hipFree(h->lap_flags_dev);
+    if (h->lap_dev) hipFree(h->lap_dev);
     delete h->pool;
     hipStreamDestroy(h->stream);
     delete h;
@@ -1976,8 +2106,14 @@ int papof_stage_smoothflow_ex(papof_handle* h, const double* im1, const double* 
     PAPOF_TRY(sor_bind(h, B.sp, height, width, n_sor));
     PAPOF_TRY(sor_reset_planes(h, B.sp));
     PhaseClock clk{h, false};
+    LapGuard lg;  // a stage call always takes the exact pass of the Laplacian-noise guard, LapPara starting at 0.02 (:773-775)
+    lg.on = h->lap_guard && noise_model == PAPOF_NOISE_LAPLACIAN && c <= 8 && h->lap_dev != nullptr;
+    lg.exact = true;
+    lg.lap = h->lap_dev;
+    lg.scratch = h->lap_scratch_dev;
+    if (lg.on) PAPOF_HIP(hipMemcpyAsync(lg.lap, h->lap_init_dev, 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     PAPOF_TRY(smooth_flow(h, f1, f2, w, du, dv, du_alt, dv_alt, height, width, c, alpha, n_outer, n_inner, n_sor, omega,
-                          sor_mode, B, clk));
+                          sor_mode, B, clk, nullptr, true, nullptr, 0, nullptr, nullptr, false, &lg, 0));
     PAPOF_TRY(S.down_planar(w, warp, height, width, c));
     PAPOF_TRY(S.down_planar(du, u, height, width, 1));
     PAPOF_TRY(S.down_planar(dv, v, height, width, 1));
@@ -2098,6 +2234,15 @@ int papof_last_sor_stats(papof_handle* h, int* launches, double* strip_streams_s
     if (!h) return PAPOF_EINVAL;
     if (launches) *launches = h->sor_launches;
     if (strip_streams_sec) *strip_streams_sec = h->sor_upper_sec;
+    return PAPOF_OK;
+}
+
+int papof_lap_guard_stats(papof_handle* h, int out[4]) {
+    if (!h || !out) return PAPOF_EINVAL;
+    out[0] = h->lap_reruns;
+    out[1] = h->lap_exact_calls;
+    out[2] = h->lap_exact ? 1 : 0;
+    out[3] = h->lap_guard ? 1 : 0;
     return PAPOF_OK;
 }
 

@@ -84,6 +84,10 @@ struct Arena {
     void release(size_t m) { off = m; }
 };
 
+constexpr int kLapNzWords = 32 * 8, kLapMaxSlots = 1024;  // flags of the Laplacian-noise guard (papof_handle::lap_flags_dev)
+constexpr size_t kLapFlagWords = (size_t)kLapMaxSlots * 8 + kLapNzWords;
+inline size_t lap_wit_word(int slot) { return (size_t)(kLapMaxSlots - 1 - slot) * 8; }  // slots grow DOWNWARDS towards ...
+inline size_t lap_nz_word(int level) { return (size_t)kLapMaxSlots * 8 + (size_t)level * 8; }  // ... the non-zero flags
 constexpr int kSorMaxDepth = 32;  // largest software-pipeline depth (steps) of the exact-order SOR kernel
 constexpr int kBandRows = kLanes - 2;  // real rows per task: lanes 1..62; lanes 0 / 63 stand for the rows above / below
 
@@ -278,6 +282,20 @@ struct papof_handle {
     // second stream for everything that does not depend on the flow (pyramids, features, smoothed frame 1 of every
     // level, derivative planes of the final bicubic warp): runs beside the coarse levels' latency-bound solves
     hipStream_t prep_stream = nullptr;
+    // Laplacian-noise guard (api.hip: LapGuard; src/OpticalFlow.cpp:399-400, :594-639).  Flags of a call, device + page-locked
+    // host copy, ONE block shared with the phase stamps so that one copy per call fetches both: 8 witness words per outer
+    // iteration (slot s at word (kLapMaxSlots - 1 - s) * 8: the used slots end where the next part begins), kLapNzWords words
+    // of per-level non-zero flags of the feature channels, then the stamps.  lap_dev: LapPara of the exact pass (8 doubles),
+    // its initial value 0.02 (:773-775) as a device constant, the reduction's scratch.
+    unsigned* lap_flags_dev = nullptr;
+    unsigned* lap_flags_host = nullptr;
+    double* lap_dev = nullptr;
+    double* lap_init_dev = nullptr;
+    double* lap_scratch_dev = nullptr;
+    bool lap_guard = true;     // PAPOF_LAP_GUARD=0: no guard at all (the optimistic pass without witnesses: A/B of their cost)
+    bool lap_exact = false;    // the next call starts in the exact pass (its predecessor ended with a channel lacking a proof)
+    unsigned lap_epoch = 0;    // a flag is SET when it holds the number of the pass that wrote it: nothing is ever cleared
+    int lap_reruns = 0, lap_exact_calls = 0;  // statistics (papof_lap_guard_stats)
     // Host buffers handed to the call itself (flow_host -> flow_device): the call then issues the PCIe copies where they
     // overlap device work -- frame 2 uploads while frame 1's share of the preparation runs, (vx, vy) go back beside the
     // final bicubic warp, warpI2 in row chunks behind its kernel's chunks -- on a stream of their own.
@@ -335,7 +353,7 @@ int filter_hv(papof_handle* h, const double* src, double* dst, double* tmp, int 
               const Taps& fv);  // both passes in one launch (same bits); `tmp` only for half-widths beyond the fused kernel's
 int resize(papof_handle* h, const double* src, double* dst, int sh, int sw, int planes, int dh, int dw, double xr,
            double yr, bool use_post, double post, const Rect* rc = nullptr);
-int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C);
+int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C, unsigned* nz = nullptr);
 int central3_planes(papof_handle* h, const double* src, double* gx, double* gy, double* gxy, int H, int W, int planes);
 int warp_bilinear(papof_handle* h, const double* im1, const double* im2, const double* vx, const double* vy,
                   double* out, int H, int W, int planes, const Rect* rc = nullptr);
@@ -344,13 +362,16 @@ int smooth_v_blend(papof_handle* h, const double* tmp, const double* im1s, doubl
 int smooth_hv_blend(papof_handle* h, const double* warp, const double* im1s, double* blend, double* imdt, int H,
                     int W, int planes, int row0 = 0, int row1 = -1);  // rows row0 .. row1-1 (-1: to the last row)
 int warp_smooth_blend(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v,
-                      const double* im1s, double* blend, double* imdt, int H, int W, int planes);  // warp folded in
+                      const double* im1s, double* blend, double* imdt, int H, int W, int planes, unsigned* wit = nullptr);  // warp folded in
 int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlanes* prev, double* phi, int H, int W,
                 const Rect* rc = nullptr);
 int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,
                     const double* v, int H, int W, int planes, double alpha, double omega, const SorPlanes& out,
                     double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev, const Rect* rc = nullptr,
-                    const double* gm = nullptr);
+                    const double* gm = nullptr, const double* lap = nullptr);
+int lap_scratch_doubles();
+int est_laplacian_noise(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H,
+                        int W, int C, double* lap, double* scratch);  // the exact pass of the Laplacian-noise guard
 int gm_scratch_doubles();
 int est_gaussian_mixture(papof_handle* h, const double* im1, const double* im2, int H, int W, int C, double* gm,
                          double* scratch);
@@ -365,7 +386,7 @@ int flow_dequantize16(papof_handle* h, const unsigned short* q, double* vx, doub
 int flow_to_bgr(papof_handle* h, const double* vx, const double* vy, size_t n, double* partial, unsigned char* bgr);
 int update_warp_phi(papof_handle* h, const SorPlanes& sp, const double* u, const double* v, double* u_out, double* v_out,
                     const double* im1, const double* im2, double* warp, double* phi_out, int H, int W, int planes,
-                    bool do_warp = true, int row0 = 0, int row1 = -1);
+                    bool do_warp = true, int row0 = 0, int row1 = -1, unsigned* wit = nullptr);
 int update_flow(papof_handle* h, const SorPlanes& sp, double* u, double* v, int H, int W, const Rect& r);
 int sor_prep(papof_handle* h, const double* phi, const double* imdxy, const double* imdx2, const double* imdy2,
              const double* rhs1, const double* rhs2, int H, int W, double alpha, double omega, const SorPlanes& out);

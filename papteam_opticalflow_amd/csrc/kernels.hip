@@ -213,7 +213,10 @@ __global__ void k_im2feature(const double* __restrict__ im, double* __restrict__
 constexpr int kFeatRows = PAPOF_V_FEATROWS;
 template <int C>
 __global__ __launch_bounds__(256) void k_im2feature_tiled(const double* __restrict__ im, double* __restrict__ feat, int H,
-                                                          int W, Taps d) {
+                                                          int W, Taps d, unsigned* __restrict__ nz, unsigned mark) {
+    // nz (may be null): nz[k] is set when feature channel k has a non-zero value anywhere -- a channel that is all zero in BOTH
+    // frames has no valid sample for estLaplacianNoise (every |Im1 - warpIm2| is exactly 0), so its LapPara is 0.001 whatever
+    // the flow (api.hip: LapGuard).  One ballot per wave, at most one store per wave and channel.
     __shared__ double g[kFeatRows + 4][BX + 4];
     const int j0 = blockIdx.x * BX, i0 = blockIdx.y * kFeatRows;
     const size_t np = (size_t)H * W;
@@ -223,24 +226,38 @@ __global__ __launch_bounds__(256) void k_im2feature_tiled(const double* __restri
     }
     __syncthreads();
     const int j = j0 + threadIdx.x;
-    if (j >= W) return;
-    for (int r = threadIdx.y; r < kFeatRows; r += BY) {
-        const int i = i0 + r;
-        if (i >= H) break;
-        const size_t o = (size_t)i * W + j;
-        double gx = 0.0, gy = 0.0;
+    bool any[5] = {false, false, false, false, false};
+    if (j < W) {
+        for (int r = threadIdx.y; r < kFeatRows; r += BY) {
+            const int i = i0 + r;
+            if (i >= H) break;
+            const size_t o = (size_t)i * W + j;
+            double gx = 0.0, gy = 0.0;
 #pragma unroll
-        for (int l = -2; l <= 2; l++) gx += g[r + 2][threadIdx.x + 2 + l] * d.t[l + 2];
+            for (int l = -2; l <= 2; l++) gx += g[r + 2][threadIdx.x + 2 + l] * d.t[l + 2];
 #pragma unroll
-        for (int l = -2; l <= 2; l++) gy += g[r + 2 + l][threadIdx.x + 2] * d.t[l + 2];
-        feat[o] = g[r + 2][threadIdx.x + 2];
-        feat[np + o] = gx;
-        feat[2 * np + o] = gy;
-        if (C == 3) {
-            const double gg = im[np + o];
-            feat[3 * np + o] = gg - im[o];
-            feat[4 * np + o] = gg - im[2 * np + o];
+            for (int l = -2; l <= 2; l++) gy += g[r + 2 + l][threadIdx.x + 2] * d.t[l + 2];
+            const double f0 = g[r + 2][threadIdx.x + 2];
+            feat[o] = f0;
+            feat[np + o] = gx;
+            feat[2 * np + o] = gy;
+            any[0] |= f0 != 0.0;
+            any[1] |= gx != 0.0;
+            any[2] |= gy != 0.0;
+            if (C == 3) {
+                const double gg = im[np + o];
+                const double f3 = gg - im[o], f4 = gg - im[2 * np + o];
+                feat[3 * np + o] = f3;
+                feat[4 * np + o] = f4;
+                any[3] |= f3 != 0.0;
+                any[4] |= f4 != 0.0;
+            }
         }
+    }
+    if (nz != nullptr) {
+#pragma unroll
+        for (int k = 0; k < (C == 3 ? 5 : 3); k++)
+            if (__ballot(any[k]) != 0ull && threadIdx.x == 0) nz[k] = mark;
     }
 }
 
@@ -383,7 +400,8 @@ __global__ __launch_bounds__(256) void k_warp_smooth_blend(const double* __restr
                                                            const double* __restrict__ u, const double* __restrict__ v,
                                                            const double* __restrict__ im1s, double* __restrict__ blend,
                                                            double* __restrict__ imdt, int H, int W, Taps g,
-                                                           unsigned long long* stamp) {
+                                                           unsigned long long* stamp, unsigned* __restrict__ wit,
+                                                           double wit_thr, unsigned mark) {
     // one channel per block (blockIdx.z).  [Also measured: one block looping over the channels with the sampling taps of its
     // cells kept in registers -- 0.2 ms per 1080p pair SLOWER (register pressure, ten barriers per block).]
     __shared__ double raw[kWsRows + 4][BX + 4];
@@ -392,6 +410,19 @@ __global__ __launch_bounds__(256) void k_warp_smooth_blend(const double* __restr
     const int j0 = blockIdx.x * BX, i0 = blockIdx.y * kWsRows;
     const size_t np = (size_t)H * W;
     const double *p1 = im1 + blockIdx.z * np, *p2 = im2 + blockIdx.z * np;
+    // WITNESS for the Laplacian-noise guard (api.hip: LapGuard): estLaplacianNoise (src/OpticalFlow.cpp:594-639) averages
+    // |Im1 - warpIm2| over its samples in (0, 1e6), and ONE sample of at least wit_thr = 2e-20 x pixels proves that mean is not
+    // below 1e-20 (a sum of positives is at least its largest term), i.e. that the guard of :399-400 did not trip.  This kernel
+    // evaluates exactly that warp -- frame 2 at the flow the previous outer iteration left -- so the first wave of every
+    // block compares 64 cells spread over the tile (their frame-1 values are fetched here, beside the gathers: no latency of
+    // their own; halo cells are clamped copies of image pixels, warped as such: as good a sample as any).
+    // Where the grid is large, one block in sixteen samples: thousands of stores to one word are not free.
+    const bool sampler = wit != nullptr && threadIdx.y == 0u &&
+                         (gridDim.x * gridDim.y <= 256u || ((blockIdx.x + 5u * blockIdx.y) & 15u) == 0u);
+    constexpr int kWitStride = (kWsRows + 4) * (BX + 4) / 64;
+    const int wr = (int)(threadIdx.x * kWitStride) / (BX + 4), wc = (int)(threadIdx.x * kWitStride) - wr * (BX + 4);
+    double own1 = 0.0;
+    if (sampler) own1 = p1[(size_t)clampi(i0 + wr - 2, H) * W + clampi(j0 + wc - 2, W)];
     for (int c = threadIdx.y * BX + threadIdx.x; c < (kWsRows + 4) * (BX + 4); c += BX * BY) {
         const int r = c / (BX + 4), cc = c - r * (BX + 4);
         const int i = clampi(i0 + r - 2, H), j = clampi(j0 + cc - 2, W);
@@ -399,6 +430,11 @@ __global__ __launch_bounds__(256) void k_warp_smooth_blend(const double* __restr
         raw[r][cc] = warp_value(p1, p2, u[o], v[o], i, j, H, W);
     }
     __syncthreads();
+    if (sampler) {
+        const double d = fabs(own1 - raw[wr][wc]);
+        const unsigned long long hits = __ballot(d >= wit_thr && d < 1000000);
+        if (hits != 0ull && threadIdx.x == 0u) wit[blockIdx.z] = mark;
+    }
     for (int r = threadIdx.y; r < kWsRows + 4; r += BY) {
         double acc = 0.0;
 #pragma unroll
@@ -457,6 +493,9 @@ struct Increment {
     SkewIdx sk;
     const double* gm;  // Gaussian-mixture noise model (src/OpticalFlow.cpp:359-367): alpha[C], sigma[C], beta[C],
                        // sigma_square[C], beta_square[C] of GaussianMixture (src/NoiseModel.h); null = Laplacian (default)
+    const double* lap; // Laplacian noise level per channel (LapPara, estLaplacianNoise src/OpticalFlow.cpp:594-639) for the guard of
+                       // :399-400 -- psi of a channel stays 0 (Psi_1st.reset(), :333) while LapPara[k] < 1E-20; null = not consulted
+                       // (the optimistic pass of flow_device: api.hip, LapGuard)
 };
 __device__ __forceinline__ void increment_at(const Increment& I, int i, int j, int W, double& du, double& dv) {
     if (I.du == nullptr) {
@@ -615,6 +654,8 @@ __device__ __forceinline__ SystemCell assemble_cell(const double* __restrict__ b
             const double prob11 = prob1 / (2 * s2);
             const double prob22 = prob2 / (2 * b2);
             psi = (prob11 + prob22) / (prob1 + prob2);
+        } else if (I.lap != nullptr && I.lap[k] < 1E-20) {
+            psi = 0.0;  // :399-400 `continue` on the freshly reset Psi_1st (:333)
         } else {
             psi = 1 / (2 * sqrt(t + 0.001 * 0.001));
         }
@@ -827,7 +868,8 @@ __global__ void k_update_warp_phi(const double* __restrict__ sdu, const double* 
                                   double* __restrict__ u_out, double* __restrict__ v_out,
                                   const double* __restrict__ im1, const double* __restrict__ im2,
                                   double* __restrict__ warp, double* __restrict__ phi_out, int H, int W, int planes,
-                                  int do_warp, unsigned long long* stamp, int row0, int row1) {
+                                  int do_warp, unsigned long long* stamp, int row0, int row1, unsigned* __restrict__ wit,
+                                  double wit_thr, unsigned mark) {
     stamp_now(stamp);
     const int j = blockIdx.x * BX + threadIdx.x, i = row0 + blockIdx.y * BY + threadIdx.y;  // rows row0 .. row1-1
     if (j >= W || i >= row1) return;
@@ -849,6 +891,26 @@ __global__ void k_update_warp_phi(const double* __restrict__ sdu, const double* 
     fv += b;
     u_out[o] = fu;
     v_out[o] = fv;
+    // WITNESS for the Laplacian-noise guard (see k_warp_smooth_blend, which takes the witnesses wherever another outer
+    // iteration follows on the level): behind the LAST update of a level nobody evaluates the warp at the new flow, so here the
+    // first `planes` threads of every block evaluate it at their own pixel, one channel each.
+    if (wit != nullptr) {
+        const int bw = min(W - (int)(blockIdx.x * BX), BX), bh = min(row1 - (int)(row0 + blockIdx.y * BY), BY);  // the block's pixels
+        const int lin = threadIdx.y * bw + threadIdx.x;
+        const size_t np = (size_t)H * W;
+        if (np <= 65536) {  // a coarse level: few blocks, so every thread samples (channel = its number within the block mod planes)
+            for (int k = bw * bh >= planes ? lin % planes : lin; k < planes; k += bw * bh) {
+                const double w = warp_value(im1 + k * np, im2 + k * np, fu, fv, i, j, H, W);
+                const double d = fabs(im1[k * np + o] - w);
+                if (d >= wit_thr && d < 1000000) wit[k] = mark;
+            }
+        } else if (((blockIdx.x + 5u * blockIdx.y) & 15u) == 0u)  // a large grid: one block in sixteen samples
+        for (int k = lin; k < planes; k += bw * bh) {  // (one trip of one thread per channel, unless the block has fewer pixels)
+            const double w = warp_value(im1 + k * np, im2 + k * np, fu, fv, i, j, H, W);
+            const double d = fabs(im1[k * np + o] - w);
+            if (d >= wit_thr && d < 1000000) wit[k] = mark;
+        }
+    }
     if (phi_out != nullptr) {
         double ur = 0.0, vr = 0.0, ud = 0.0, vd = 0.0;
         if (j < W - 1) {
@@ -1181,13 +1243,13 @@ int resize(papof_handle* h, const double* src, double* dst, int sh, int sw, int 
     return PAPOF_OK;
 }
 
-int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C) {
+int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C, unsigned* nz) {
     if (C == 3) {
         hipLaunchKernelGGL(k_im2feature_tiled<3>, dim3((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows), dim3(BX, BY), 0,
-                           h->stream, im, feat, H, W, deriv5_taps());
+                           h->stream, im, feat, H, W, deriv5_taps(), nz, h->lap_epoch);
     } else if (C == 1) {
         hipLaunchKernelGGL(k_im2feature_tiled<1>, dim3((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows), dim3(BX, BY), 0,
-                           h->stream, im, feat, H, W, deriv5_taps());
+                           h->stream, im, feat, H, W, deriv5_taps(), nz, h->lap_epoch);
     } else {  // src/OpticalFlow.cpp:956-957: any other channel count is passed through
         PAPOF_HIP(hipMemcpyAsync(feat, im, sizeof(double) * (size_t)H * W * C, hipMemcpyDeviceToDevice, h->stream));
         return PAPOF_OK;
@@ -1221,10 +1283,10 @@ static SkewIdx skew_idx(const SorPlanes& sp) {
 }
 
 // `prev` = operands of the previous inner iteration's solve (nullptr in the first one: du = dv = 0)
-static Increment increment_of(const SorPlanes* prev, const double* gm = nullptr) {
-    if (!prev) return Increment{nullptr, nullptr, 0, SkewIdx{0, 0, 0, 0, 0, 0, 0}, gm};
+static Increment increment_of(const SorPlanes* prev, const double* gm = nullptr, const double* lap = nullptr) {
+    if (!prev) return Increment{nullptr, nullptr, 0, SkewIdx{0, 0, 0, 0, 0, 0, 0}, gm, lap};
     return Increment{prev->du, prev->dv, prev->skew ? 1 : 0, prev->skew ? skew_idx(*prev) : SkewIdx{0, 0, 0, 0, 0, 0, 0},
-                     gm};
+                     gm, lap};
 }
 
 int smooth_hv_blend(papof_handle* h, const double* warp, const double* im1s, double* blend, double* imdt, int H,
@@ -1240,9 +1302,10 @@ int smooth_hv_blend(papof_handle* h, const double* warp, const double* im1s, dou
 }
 
 int warp_smooth_blend(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v,
-                      const double* im1s, double* blend, double* imdt, int H, int W, int planes) {
+                      const double* im1s, double* blend, double* imdt, int H, int W, int planes, unsigned* wit) {
     hipLaunchKernelGGL(k_warp_smooth_blend, dim3((W + BX - 1) / BX, (H + kWsRows - 1) / kWsRows, planes), dim3(BX, BY), 0,
-                       h->stream, im1, im2, u, v, im1s, blend, imdt, H, W, smooth5_taps(), take_stamp(h));
+                       h->stream, im1, im2, u, v, im1s, blend, imdt, H, W, smooth5_taps(), take_stamp(h), wit,
+                       2e-20 * (double)H * (double)W, h->lap_epoch);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
@@ -1259,8 +1322,9 @@ int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlan
 
 int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,
                     const double* v, int H, int W, int planes, double alpha, double omega, const SorPlanes& out,
-                    double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev, const Rect* rc, const double* gm) {
-    const Increment I = increment_of(prev, gm);
+                    double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev, const Rect* rc, const double* gm,
+                    const double* lap) {
+    const Increment I = increment_of(prev, gm, lap);
     const Rect r = region(rc, W, H);
     if (r.empty()) return PAPOF_OK;
     if (out.skew) {
@@ -1299,7 +1363,8 @@ int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, 
 
 int update_warp_phi(papof_handle* h, const SorPlanes& sp, const double* u, const double* v, double* u_out, double* v_out,
                     const double* im1, const double* im2, double* warp, double* phi_out, int H, int W, int planes,
-                    bool do_warp, int row0, int row1) {
+                    bool do_warp, int row0, int row1, unsigned* wit) {
+    const double wit_thr = 2e-20 * (double)H * (double)W;
     if (u == u_out || v == v_out) return PAPOF_EINVAL;
     if (row1 < 0) row1 = H;
     if (row0 < 0 || row1 > H) return PAPOF_EINVAL;
@@ -1308,11 +1373,11 @@ int update_warp_phi(papof_handle* h, const SorPlanes& sp, const double* u, const
     if (sp.skew)
         hipLaunchKernelGGL(k_update_warp_phi<true>, grid, dim3(BX, BY), 0, h->stream, sp.du, sp.dv, skew_idx(sp),
                            u, v, u_out, v_out, im1, im2, warp, phi_out, H, W, planes, do_warp ? 1 : 0, take_stamp(h),
-                           row0, row1);
+                           row0, row1, wit, wit_thr, h->lap_epoch);
     else
         hipLaunchKernelGGL(k_update_warp_phi<false>, grid, dim3(BX, BY), 0, h->stream, sp.du, sp.dv,
                            SkewIdx{0, 0, 0, 0, 0, 0, 0, 0, 0}, u, v, u_out, v_out, im1, im2, warp, phi_out, H, W, planes,
-                           do_warp ? 1 : 0, take_stamp(h), row0, row1);
+                           do_warp ? 1 : 0, take_stamp(h), row0, row1, wit, wit_thr, h->lap_epoch);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
@@ -1442,6 +1507,69 @@ int est_gaussian_mixture(papof_handle* h, const double* im1, const double* im2, 
                            scratch);
         hipLaunchKernelGGL(k_gm_mstep, dim3(1), dim3(64), 0, h->stream, scratch, C, 0.9, gm);
     }
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// OpticalFlow::estLaplacianNoise, src/OpticalFlow.cpp:594-639, for the EXACT pass of the Laplacian-noise guard (api.hip:
+// LapGuard; only calls whose optimistic pass found a channel without a witness get here): per channel the mean of
+// |Im1 - warpIm2| over the samples in (0, 1e6), 0.001 when there is none.  The warped frame is evaluated on the fly (it is
+// never materialised on this path; u == nullptr: im2 is the warped frame, the bicubic branch).  One reduction kernel (per block: sum and count in a fixed tree) + one single-block
+// kernel that adds the blocks' partials in block order: deterministic; the reference adds sequentially over the pixels, so
+// the mean can differ in its last bits -- it only feeds the `< 1E-20` test.
+// ------------------------------------------------------------------------------------------------
+constexpr int kLapBlocks = 256, kLapThreads = 256, kLapMaxC = 8;
+static __global__ __launch_bounds__(kLapThreads) void k_lap_partial(const double* __restrict__ im1,
+                                                             const double* __restrict__ im2,
+                                                             const double* __restrict__ u, const double* __restrict__ v,
+                                                             int H, int W, int C, double* __restrict__ partial) {
+    __shared__ double red[kLapThreads];
+    const size_t np = (size_t)H * W;
+    double acc[kLapMaxC][2];
+    for (int k = 0; k < kLapMaxC; k++) acc[k][0] = acc[k][1] = 0.0;
+    for (size_t o = (size_t)blockIdx.x * kLapThreads + threadIdx.x; o < np; o += (size_t)kLapBlocks * kLapThreads) {
+        const int i = (int)(o / W), j = (int)(o - (size_t)i * W);
+        const double fu = u ? u[o] : 0.0, fv = u ? v[o] : 0.0;  // u == nullptr: im2 IS the warped frame (bicubic branch)
+#pragma unroll
+        for (int k = 0; k < kLapMaxC; k++) {
+            if (k >= C) break;
+            const double w = u ? warp_value(im1 + k * np, im2 + k * np, fu, fv, i, j, H, W) : im2[k * np + o];
+            const double d = fabs(im1[k * np + o] - w);
+            if (d > 0 && d < 1000000) {
+                acc[k][0] += d;
+                acc[k][1] += 1.0;
+            }
+        }
+    }
+    for (int k = 0; k < C; k++)
+        for (int q = 0; q < 2; q++) {
+            red[threadIdx.x] = acc[k][q];
+            __syncthreads();
+            for (int s = kLapThreads / 2; s > 0; s >>= 1) {
+                if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) partial[((size_t)blockIdx.x * kLapMaxC + k) * 2 + q] = red[0];
+            __syncthreads();
+        }
+}
+static __global__ void k_lap_finish(const double* __restrict__ partial, int C, double* __restrict__ lap) {
+    const int k = threadIdx.x;
+    if (k >= C) return;
+    double s = 0.0, n = 0.0;
+    for (int b = 0; b < kLapBlocks; b++) {
+        s += partial[((size_t)b * kLapMaxC + k) * 2];
+        n += partial[((size_t)b * kLapMaxC + k) * 2 + 1];
+    }
+    lap[k] = n == 0 ? 0.001 : s / n;
+}
+int lap_scratch_doubles() { return kLapBlocks * kLapMaxC * 2; }
+int est_laplacian_noise(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H,
+                        int W, int C, double* lap, double* scratch) {
+    if (C > kLapMaxC) return PAPOF_EINVAL;
+    hipLaunchKernelGGL(k_lap_partial, dim3(kLapBlocks), dim3(kLapThreads), 0, h->stream, im1, im2, u, v, H, W, C, scratch);
+    hipLaunchKernelGGL(k_lap_finish, dim3(1), dim3(64), 0, h->stream, scratch, C, lap);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }

@@ -606,13 +606,123 @@ def test_flow_visualisation_matches_its_numpy_restatement(gpu):
     assert tuple(r[0, 0]) == (0, 0, 255) and not r[0, 1].any()  # rightward motion: hue 0 = red, full value
 
 
-@pytest.mark.xfail(strict=True, reason="known, documented gap (DESIGN.md 0, row a16): the GPU path does not run estLaplacianNoise, so "
-                   "the `LapPara[k] < 1E-20 => psi = 0` guard (src/OpticalFlow.cpp:399-400) is not reproduced; unreachable for "
-                   "8-bit frames (a channel's mean |Im1 - warpIm2| over its non-zero samples cannot fall below 1e-20)")
 def test_laplacian_noise_guard_tripping_case(gpu, oracle):
-    """The golden case `stage_lapguard` (tests/golden/cases.py) -- inputs on which the reference's guard trips, pinned bit for
-    bit between the oracle and the untouched reference -- through the GPU stage: strict xfail until the guard is built."""
+    """The golden case `stage_lapguard` (tests/golden/cases.py) -- inputs on which the reference's `LapPara[k] < 1E-20`
+    guard (src/OpticalFlow.cpp:399-400, fed by estLaplacianNoise, :594-639) trips, pinned bit for bit between the oracle and
+    the untouched reference -- through the GPU stage (which always runs the exact pass of the guard, api.hip: LapGuard),
+    against the oracle AND against the reference's own numbers in golden.npz."""
     f1, f2, z, alpha = cases.lapguard_inputs()
     got = gpu.smoothflow_sor(f1, f2, f2, z, z, alpha, 3, 1, 5)
     want = oracle.smoothflow_sor(f1, f2, f2, z, z, alpha, 3, 1, 5)
     assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    gold = np.load(os.path.join(GOLD, "golden.npz"))
+    for k, a in cases.stage_lapguard(gpu).items():
+        w = gold["stage_lapguard|" + k]
+        assert np.array_equal(cases.subsample(a), w), "stage_lapguard/%s: max-abs %.3e" % (k, np.abs(cases.subsample(a) - w).max())
+
+
+def _tiny_scale_pair(res="240", scale=1e-21):
+    """float frames whose every |Im1 - warpIm2| is ~1e-21: each feature channel's noise estimate is below 1E-20 from the
+    first outer iteration on, so the reference's guard leaves every psi at 0 from the second one on"""
+    a, b = cases.load_pair(res)
+    return np.ascontiguousarray(a * scale), np.ascontiguousarray(b * scale)
+
+
+def _rel(got, want):
+    return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-300))
+
+
+def test_laplacian_noise_guard_whole_call_rerun_and_sticky_exact_pass(oracle):
+    """The guard inside the WHOLE call.  A pair on which it trips: the optimistic pass ends without proofs, the call is run
+    again in the exact pass (reruns 0 -> 1) and agrees with the oracle; the next call on the handle starts in the exact pass
+    (no second run); an ordinary pair then runs once in the exact pass -- with the same bits as on a fresh handle -- proves
+    the pass unnecessary, and the handle is back to the optimistic pass."""
+    from papteam_opticalflow_amd import Papof
+    g = Papof(0)
+    try:
+        assert g.lap_guard_stats() == dict(reruns=0, exact_calls=0, exact_next=False, guard_on=True)
+        a, b = _tiny_scale_pair()
+        want = oracle.coarse2fine_flow(a, b, 3)[:3]
+        assert np.abs(want[0]).max() > 0
+        got = g.coarse2fine_flow(a, b, 3)[:3]
+        st = g.lap_guard_stats()
+        assert st["reruns"] == 1 and st["exact_next"] is True, st
+        for name, x, w in zip(("vx", "vy", "warpI2"), got, want):
+            assert _rel(x, w) <= 1e-9, "%s: relative difference %.3e" % (name, _rel(x, w))
+            print("tripping pair, %s: relative difference to the oracle %.3e %s" % (name, _rel(x, w), "(bit-exact)" if np.array_equal(x, w) else ""))
+        again = g.coarse2fine_flow(a, b, 3)[:3]
+        st = g.lap_guard_stats()
+        assert st["reruns"] == 1 and st["exact_calls"] == 1 and st["exact_next"] is True, st
+        for x, w in zip(again, got):
+            assert np.array_equal(x, w)
+        # an ordinary pair: once in the exact pass, then optimistic again; the two passes give the same bits
+        p, q = cases.load_pair("240")
+        first = g.coarse2fine_flow(p, q, 3)[:3]
+        st = g.lap_guard_stats()
+        assert st["reruns"] == 1 and st["exact_calls"] == 2 and st["exact_next"] is False, st
+        second = g.coarse2fine_flow(p, q, 3)[:3]
+        assert g.lap_guard_stats() == dict(reruns=1, exact_calls=2, exact_next=False, guard_on=True)
+        for x, w in zip(first, second):
+            assert np.array_equal(x, w)
+    finally:
+        g.close()
+
+
+def test_laplacian_noise_guard_switch_is_what_makes_the_difference(oracle, monkeypatch):
+    """PAPOF_LAP_GUARD=0 (an A/B switch for the guard's cost) on the tripping pair: far from the oracle -- i.e. the test above
+    does tell a path with the guard from one without."""
+    from papteam_opticalflow_amd import Papof
+    a, b = _tiny_scale_pair()
+    want = oracle.coarse2fine_flow(a, b, 3)[0]
+    monkeypatch.setenv("PAPOF_LAP_GUARD", "0")
+    g = Papof(0)
+    try:
+        got = g.coarse2fine_flow(a, b, 3)[0]
+        assert g.lap_guard_stats()["guard_on"] is False and g.lap_guard_stats()["reruns"] == 0
+    finally:
+        g.close()
+    assert _rel(got, want) > 1e-3
+
+
+@pytest.mark.parametrize("kind", ["rgb_u8", "gray_u8", "gray_as_rgb", "float", "sequence", "identical", "black", "deep"])
+def test_laplacian_noise_guard_never_reruns_ordinary_input(kind):
+    """Ordinary inputs end the optimistic pass with a proof for every consulted estimate -- a witness sample, or a feature
+    channel that is zero throughout (gray content in three channels: G-R and G-B; black frames) -- and run ONCE."""
+    from papteam_opticalflow_amd import Papof
+    g = Papof(0)
+    try:
+        a, b = cases.load_pair("240")
+        a8, b8 = (np.clip(np.rint(a * 255), 0, 255).astype(np.uint8) for a in (a, b))
+        levels = 3
+        if kind == "rgb_u8":
+            g.coarse2fine_flow_u8(a8, b8, levels)
+        elif kind == "gray_u8":
+            g.coarse2fine_flow_u8(np.ascontiguousarray(a8[..., :1]), np.ascontiguousarray(b8[..., :1]), levels)
+        elif kind == "gray_as_rgb":
+            ga, gb = (np.ascontiguousarray(np.repeat(x[..., 1:2], 3, axis=2)) for x in (a8, b8))
+            g.coarse2fine_flow_u8(ga, gb, levels)
+        elif kind == "float":
+            g.coarse2fine_flow(a, b, levels)
+        elif kind == "sequence":
+            for f in (a8, b8, a8, b8):
+                g.seq_push(f, levels)
+        elif kind == "identical":  # no valid sample anywhere: LapPara = 0.001 -- but nothing proves it: see below
+            pass
+        elif kind == "black":
+            z = np.zeros_like(a8)
+            g.coarse2fine_flow_u8(z, z, levels)
+        elif kind == "deep":
+            g.coarse2fine_flow_u8(a8, b8, 12)
+        st = g.lap_guard_stats()
+        if kind != "identical":
+            assert st["reruns"] == 0 and st["exact_calls"] == 0 and st["exact_next"] is False, (kind, st)
+        else:
+            # duplicate frames: every |Im1 - warpIm2| is exactly 0 while the flow stays 0 -- no witness exists, the call is run
+            # again in the exact pass (where LapPara = 0.001 keeps the guard open): same results, twice the time, and the
+            # handle stays in the exact pass while the frames stay duplicates
+            r1 = g.coarse2fine_flow_u8(a8, a8, levels)[:3]
+            st = g.lap_guard_stats()
+            assert st["reruns"] == 1 and st["exact_next"] is True, st
+            assert not r1[0].any() and not r1[1].any()
+    finally:
+        g.close()
