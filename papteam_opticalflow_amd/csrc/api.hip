@@ -334,7 +334,8 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
             // warp + both passes + blend + imdt; the warp at the flow the previous iteration left is what that iteration's
             // noise estimate is about: its witnesses are taken here (LapGuard)
             PAPOF_TRY(warp_smooth_blend(h, f1, f2, u, v, im1s, B.blend, B.imdt, H, W, fc,
-                                        lg && count > 0 && !B.gm ? lg->wit(lg->slot - 1) : nullptr));
+                                        lg && count > 0 && !B.gm ? lg->wit(lg->slot - 1) : nullptr,
+                                        count == 0 ? B.phi : nullptr));  // ... and phi of the level's initial flow
         else
             PAPOF_TRY(smooth_hv_blend(h, warp, im1s, B.blend, B.imdt, H, W, fc));  // both passes + blend + imdt, fused
         // inner fixed-point iterations (src/OpticalFlow.cpp:290-506): after the first one, phi is taken at u + du and
@@ -343,7 +344,7 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
             const SorPlanes* prev = hh == 0 ? nullptr : &SP;
             // phi (Phase2): of the level's initial flow, and inside further inner iterations (at u + du), by its own kernel;
             // for every later outer iteration the previous iteration's update kernel has written it already
-            if (count == 0 || hh > 0) {
+            if ((count == 0 && !fold_warp) || hh > 0) {  // (fold_warp: warp_smooth_blend wrote the level's first phi)
                 clk.phase(PAPOF_T_PHASE2_DERIVATIVES);
                 PAPOF_TRY(compute_phi(h, u, v, prev, B.phi, H, W));
             }
@@ -812,10 +813,12 @@ int flow_pass(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, i
     double* gy = A.f64(np0 * C);
     double* gxy = A.f64(np0 * C);
     double* warp = A.f64(np0 * fc);
-    double* u = A.f64(np0);
-    double* v = A.f64(np0);
-    double* u2 = A.f64(np0);
-    double* v2 = A.f64(np0);
+    // the flow lives in two PAIRS of planes (the update of an outer iteration writes the other pair); within a pair v follows
+    // u at the pitch of the level in work, so that the up-sampling of (u, v) is one launch and their first clear one fill
+    double* u = A.f64(2 * np0);
+    double* v = u ? u + np0 : nullptr;
+    double* u2 = A.f64(2 * np0);
+    double* v2 = u2 ? u2 + np0 : nullptr;
     SolveBuffers B;
     {
         const int rc_alloc = alloc_solve_buffers(A, H, W, fc, P.sor_mode, n_sor_max, B);
@@ -1035,24 +1038,26 @@ int flow_pass(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, i
             LevelInit li{k == levels - 1, nullptr, nullptr, ph, pw, 0.0, 0.0, 1 / ratio};
             const bool fold_warp = !strips && !B.bgx && !B.gm;  // the warped frame 2 lives only inside the smoothing kernel
             if (k == levels - 1) {  // src/OpticalFlow.cpp:801-806
-                PAPOF_HIP(hipMemsetAsync(u, 0, np * sizeof(double), h->stream));
-                PAPOF_HIP(hipMemsetAsync(v, 0, np * sizeof(double), h->stream));
+                v = u + np;
+                v2 = u2 + np;
+                PAPOF_HIP(hipMemsetAsync(u, 0, 2 * np * sizeof(double), h->stream));
                 if (!fold_warp)
                     PAPOF_HIP(hipMemcpyAsync(warp, f2, np * fc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
                 if (B.bgx) PAPOF_TRY(bicubic_planes(h, f2, lh, lw, fc, B));
             } else {  // :809-816
                 const double xr = (double)lw / pw, yr = (double)lh / ph, inv = 1 / ratio;
+                v2 = u2 + np;  // the pair that receives this level's flow, at this level's pitch
                 if (strips) {  // up-sampling and warp happen per strip
                     li.pu = u;
                     li.pv = v;
                     li.xr = xr;
                     li.yr = yr;
                 } else {
-                    PAPOF_TRY(resize(h, u, u2, ph, pw, 1, lh, lw, xr, yr, true, inv));
-                    PAPOF_TRY(resize(h, v, v2, ph, pw, 1, lh, lw, xr, yr, true, inv));
+                    PAPOF_TRY(resize(h, u, u2, ph, pw, 2, lh, lw, xr, yr, true, inv));  // u and v: two planes of one launch
                 }
                 std::swap(u, u2);
                 std::swap(v, v2);
+                v2 = u2 + np;  // the free pair, at this level's pitch too
                 if (strips || fold_warp) {
                 } else if (!B.bgx) {
                     PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc));
@@ -1159,6 +1164,15 @@ int flow_pass(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, i
         const double fused = tm[PAPOF_T_PHASE4_LINEARSYSTEM];
         tm[PAPOF_T_PHASE3_PSIDATA] += kPsiShare * fused;
         tm[PAPOF_T_PHASE4_LINEARSYSTEM] = fused - kPsiShare * fused;
+    }
+    {   // phi (Phase2_Derivatives, :295-331) has no kernel of its own on the default path any more: the update kernel writes
+        // the next iteration's (recorded under Phase6), the level's first smoothing kernel the initial one.  kPhiShare = phi's
+        // part of the update kernel -- 6 of its 14 memory streams, the square root and the division -- as a fixed
+        // apportioning of Phase6, not a measurement; a Phase2 measured by compute_phi() (inner iterations, strips) adds to it.
+        constexpr double kPhiShare = 0.4;
+        const double fused = tm[PAPOF_T_PHASE6_UPDATE];
+        tm[PAPOF_T_PHASE2_DERIVATIVES] += kPhiShare * fused;
+        tm[PAPOF_T_PHASE6_UPDATE] = fused - kPhiShare * fused;
     }
     if (timing) std::memcpy(timing, tm, sizeof tm);
     if (op == kSeqNext) keep(slot1 ^ 1);  // the frame just solved against becomes frame 1 of the next push

@@ -133,7 +133,8 @@ inline SkewDims skew_dims(int h, int w, int n_sor, int group = 1, int fuse = 1) 
         const int last = (n_sor + 1) / 2 - 1;  // index of the last pair of sweeps
         d.band_rows = kFusedRows;
         d.nb = (h + 2 * last + 1 + kFusedRows - 1) / kFusedRows;
-        d.rt = d.qt = n_sor + 3;
+        d.qt = n_sor + 3;
+        d.rt = (d.qt + 7) / 8 * 8;  // row 0 on a 128-byte boundary of its position: 16-row chunks of the assembly kernel are whole lines
         d.hp = (d.rt + kFusedRows * d.nb + 4 + 7) / 8 * 8;
         d.npos = d.qt + d.ns + 2 * kSorMaxDepth + 2 + kFusedRows * (d.nb - 1) + 2;
         d.dpar = last & 1;
@@ -143,7 +144,8 @@ inline SkewDims skew_dims(int h, int w, int n_sor, int group = 1, int fuse = 1) 
     } else {
         d.band_rows = kBandRows;
         d.nb = (h + n_sor - 1 + kBandRows - 1) / kBandRows;
-        d.rt = d.qt = n_sor + 1;
+        d.qt = n_sor + 1;
+        d.rt = (d.qt + 7) / 8 * 8;
         d.hp = (d.rt + kBandRows * d.nb + 2 + 7) / 8 * 8;
         d.npos = d.qt + d.ns + 2 * kSorMaxDepth + 2 + kBandRows * (d.nb - 1) + 2;
         d.dpar = d.group == 1 ? ((n_sor - 1) & 1) : (((n_sor + d.group - 1) / d.group - 1) & 1);
@@ -362,7 +364,8 @@ int smooth_v_blend(papof_handle* h, const double* tmp, const double* im1s, doubl
 int smooth_hv_blend(papof_handle* h, const double* warp, const double* im1s, double* blend, double* imdt, int H,
                     int W, int planes, int row0 = 0, int row1 = -1);  // rows row0 .. row1-1 (-1: to the last row)
 int warp_smooth_blend(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v,
-                      const double* im1s, double* blend, double* imdt, int H, int W, int planes, unsigned* wit = nullptr);  // warp folded in
+                      const double* im1s, double* blend, double* imdt, int H, int W, int planes, unsigned* wit = nullptr,
+                      double* phi_out = nullptr);  // phi_out: also phi of (u, v) (compute_phi without an increment)  // warp folded in
 int compute_phi(papof_handle* h, const double* u, const double* v, const SorPlanes* prev, double* phi, int H, int W,
                 const Rect* rc = nullptr);
 int assemble_system(papof_handle* h, const double* blend, const double* imdt, const double* phi, const double* u,

@@ -395,13 +395,17 @@ __device__ __forceinline__ double warp_value(const double* __restrict__ im1, con
 #ifndef PAPOF_V_WSROWS
 #define PAPOF_V_WSROWS 16
 #endif
+#ifndef PAPOF_V_WSBATCH
+#define PAPOF_V_WSBATCH 3
+#endif
+constexpr int kWsBatch = PAPOF_V_WSBATCH;  // cells per thread whose gathers are in flight together (k_warp_smooth_blend)
 constexpr int kWsRows = PAPOF_V_WSROWS;  // rows per block of the warp-folded smoothing (32 rows: 0.13 ms per 1080p pair slower)
 __global__ __launch_bounds__(256) void k_warp_smooth_blend(const double* __restrict__ im1, const double* __restrict__ im2,
                                                            const double* __restrict__ u, const double* __restrict__ v,
                                                            const double* __restrict__ im1s, double* __restrict__ blend,
                                                            double* __restrict__ imdt, int H, int W, Taps g,
                                                            unsigned long long* stamp, unsigned* __restrict__ wit,
-                                                           double wit_thr, unsigned mark) {
+                                                           double wit_thr, unsigned mark, double* __restrict__ phi_out) {
     // one channel per block (blockIdx.z).  [Also measured: one block looping over the channels with the sampling taps of its
     // cells kept in registers -- 0.2 ms per 1080p pair SLOWER (register pressure, ten barriers per block).]
     __shared__ double raw[kWsRows + 4][BX + 4];
@@ -423,11 +427,66 @@ __global__ __launch_bounds__(256) void k_warp_smooth_blend(const double* __restr
     const int wr = (int)(threadIdx.x * kWitStride) / (BX + 4), wc = (int)(threadIdx.x * kWitStride) - wr * (BX + 4);
     double own1 = 0.0;
     if (sampler) own1 = p1[(size_t)clampi(i0 + wr - 2, H) * W + clampi(j0 + wc - 2, W)];
-    for (int c = threadIdx.y * BX + threadIdx.x; c < (kWsRows + 4) * (BX + 4); c += BX * BY) {
-        const int r = c / (BX + 4), cc = c - r * (BX + 4);
-        const int i = clampi(i0 + r - 2, H), j = clampi(j0 + cc - 2, W);
-        const size_t o = (size_t)i * W + j;
-        raw[r][cc] = warp_value(p1, p2, u[o], v[o], i, j, H, W);
+    // The tile's cells (halo of 2 included) are warped in BATCHES of kWsBatch cells per thread: first the flow of every cell of
+    // the batch, then all their taps and the 4 x kWsBatch gathers, then the blends -- two dependent memory round trips per
+    // batch instead of two per cell (the kernel was bound by those: 130 us at level 0 against ~45 us of HBM traffic).  Same
+    // expressions as warp_value(): same bits.
+    constexpr int kCells = (kWsRows + 4) * (BX + 4), kPer = (kCells + BX * BY - 1) / (BX * BY);
+    const int tid = threadIdx.y * BX + threadIdx.x;
+#pragma unroll
+    for (int q0 = 0; q0 < kPer; q0 += kWsBatch) {
+        double fx[kWsBatch], fy[kWsBatch], val[kWsBatch][4];
+        int off[kWsBatch];
+#pragma unroll
+        for (int q = 0; q < kWsBatch; q++) {
+            const int c = min(tid + (q0 + q) * BX * BY, kCells - 1);  // (a thread beyond the tile repeats the last cell: discarded)
+            const int r = c / (BX + 4), cc = c - r * (BX + 4);
+            const int i = clampi(i0 + r - 2, H), j = clampi(j0 + cc - 2, W);
+            off[q] = i * W + j;
+            fx[q] = u[off[q]];
+            fy[q] = v[off[q]];
+        }
+        bool outside[kWsBatch];
+#pragma unroll
+        for (int q = 0; q < kWsBatch; q++) {
+            const int c = min(tid + (q0 + q) * BX * BY, kCells - 1);
+            const int r = c / (BX + 4), cc = c - r * (BX + 4);
+            const int i = clampi(i0 + r - 2, H), j = clampi(j0 + cc - 2, W);
+            double y = i + fy[q], x = j + fx[q];
+            outside[q] = x < 0 || x > W - 1 || y < 0 || y > H - 1;  // warp_value(): such a pixel takes frame 1's value
+            if (outside[q]) {  // (any valid position: its gathers are issued and not used)
+                x = j;
+                y = i;
+            }
+            // bilinear_taps() for a position INSIDE the image: 0 <= (int)x <= W-1 needs no clamp from below, dx = x - (int)x is in
+            // [0, 1) as it is, |1 - dx| = 1 - dx and |0 - dx| = dx -- the same values with a third of the instructions
+            const int x0 = (int)x, y0 = (int)y;
+            const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+            val[q][0] = p2[y0 * W + x0];  // visiting order of bilinear_apply(): (m, n) = (0,0) (0,1) (1,0) (1,1), tap = (x_m, y_n)
+            val[q][1] = p2[y1 * W + x0];
+            val[q][2] = p2[y0 * W + x1];
+            val[q][3] = p2[y1 * W + x1];
+            fx[q] = x - x0;
+            fy[q] = y - y0;
+        }
+#pragma unroll
+        for (int q = 0; q < kWsBatch; q++) {
+            const int c = tid + (q0 + q) * BX * BY;
+            if (c >= kCells) continue;
+            const int r = c / (BX + 4), cc = c - r * (BX + 4);
+            double res;
+            if (outside[q]) {
+                res = p1[off[q]];
+            } else {
+                const double dx = fx[q], dy = fy[q], ex = 1.0 - dx, ey = 1.0 - dy;
+                res = 0.0;
+                res += val[q][0] * (ex * ey);
+                res += val[q][1] * (ex * dy);
+                res += val[q][2] * (dx * ey);
+                res += val[q][3] * (dx * dy);
+            }
+            raw[r][cc] = res;
+        }
     }
     __syncthreads();
     if (sampler) {
@@ -457,6 +516,27 @@ __global__ __launch_bounds__(256) void k_warp_smooth_blend(const double* __restr
         t += s2 * 0.6;
         blend[o] = t;
         imdt[o] = s2 - s1;
+        // phi of the level's INITIAL flow (the first outer iteration of a level; later ones get it from the update kernel):
+        // k_phi's expressions without an increment, by the blocks of channel 0 -- one launch fewer on the level's chain
+        if (phi_out != nullptr && blockIdx.z == 0) {
+            const size_t q = (size_t)i * W + j;
+            const double uc = u[q], vc = v[q];
+            double ur = 0.0, vr = 0.0, ud = 0.0, vd = 0.0;
+            if (j < W - 1) {
+                ur = u[q + 1];
+                vr = v[q + 1];
+            }
+            if (i < H - 1) {
+                ud = u[q + W];
+                vd = v[q + W];
+            }
+            const double ux = j < W - 1 ? ur - uc : 0.0;
+            const double uy = i < H - 1 ? ud - uc : 0.0;
+            const double vx = j < W - 1 ? vr - vc : 0.0;
+            const double vy = i < H - 1 ? vd - vc : 0.0;
+            const double tt = ux * ux + uy * uy + vx * vx + vy * vy;
+            phi_out[q] = 0.5 / sqrt(tt + 0.001 * 0.001);
+        }
     }
 }
 
@@ -613,17 +693,20 @@ struct SystemCell {
 // EDGE = false: the cell is at least 2 pixels away from every image border, so no index needs clamping and every
 // neighbour exists -- the same operations in the same order with constant address offsets (the kernel is bound by
 // instruction issue, a third of it index arithmetic for the clamps).
-template <bool EDGE = true>
+// PLANES > 0: the channel count as a compile-time constant -- the channel loop is unrolled, so the stencil loads of all
+// channels are in flight together instead of one channel's per memory round trip (same operations, same order).
+template <bool EDGE = true, int PLANES = 0>
 __device__ __forceinline__ SystemCell assemble_cell(const double* __restrict__ blend, const double* __restrict__ imdt,
                                                     const double* __restrict__ phi, const double* __restrict__ u,
                                                     const double* __restrict__ v, int i, int j, int H, int W,
-                                                    int planes, double alpha, double omega, const Taps& d,
+                                                    int planes_rt, double alpha, double omega, const Taps& d,
                                                     const Increment& I) {
+    const int planes = PLANES > 0 ? PLANES : planes_rt;
     const size_t np = (size_t)H * W, o = (size_t)i * W + j;
     double sxy = 0.0, sx2 = 0.0, sy2 = 0.0, stx = 0.0, sty = 0.0;
     double du, dv;
     increment_at(I, i, j, W, du, dv);
-    for (int k = 0; k < planes; k++) {
+    const auto channel = [&](int k) {
         const double* im = blend + k * np;
         double gx = 0.0, gy = 0.0;
         if (EDGE) {
@@ -673,6 +756,13 @@ __device__ __forceinline__ SystemCell assemble_cell(const double* __restrict__ b
             stx += pgx * gt;
             sty += pgy * gt;
         }
+    };
+    if (PLANES > 0) {
+#pragma unroll
+        for (int k = 0; k < PLANES; k++) channel(k);
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < planes; k++) channel(k);
     }
     if (planes > 1) {
         sxy = sxy / planes;
@@ -751,6 +841,7 @@ constexpr int kAsmRows = PAPOF_V_ASMROWS;  // rows of the assembly kernel's tile
 struct double2s {
     double x, y;
 };
+template <int PLANES>
 __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict__ blend,
                                                        const double* __restrict__ imdt,
                                                        const double* __restrict__ phi, const double* __restrict__ u,
@@ -771,8 +862,8 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
         const int i = ib + r, j = j0 + jj;
         if (i < row1 && j < W) {
             const SystemCell s =
-                interior ? assemble_cell<false>(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I)
-                         : assemble_cell<true>(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I);
+                interior ? assemble_cell<false, PLANES>(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I)
+                         : assemble_cell<true, PLANES>(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I);
             stage[0][r][jj] = s.phi;
             stage[1][r][jj] = s.xy;
             stage[2][r][jj] = s.a1;
@@ -1302,10 +1393,11 @@ int smooth_hv_blend(papof_handle* h, const double* warp, const double* im1s, dou
 }
 
 int warp_smooth_blend(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v,
-                      const double* im1s, double* blend, double* imdt, int H, int W, int planes, unsigned* wit) {
+                      const double* im1s, double* blend, double* imdt, int H, int W, int planes, unsigned* wit,
+                      double* phi_out) {
     hipLaunchKernelGGL(k_warp_smooth_blend, dim3((W + BX - 1) / BX, (H + kWsRows - 1) / kWsRows, planes), dim3(BX, BY), 0,
                        h->stream, im1, im2, u, v, im1s, blend, imdt, H, W, smooth5_taps(), take_stamp(h), wit,
-                       2e-20 * (double)H * (double)W, h->lap_epoch);
+                       2e-20 * (double)H * (double)W, h->lap_epoch, phi_out);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
@@ -1329,7 +1421,11 @@ int assemble_system(papof_handle* h, const double* blend, const double* imdt, co
     if (r.empty()) return PAPOF_OK;
     if (out.skew) {
         if (rc && (r.x0 != 0 || r.x1 != W)) return PAPOF_EINVAL;  // skew layout: whole rows only (strips of a plane)
-        hipLaunchKernelGGL(k_assemble_skew, dim3((W + kTileJ - 1) / kTileJ, (r.y1 - r.y0 + kAsmRows - 1) / kAsmRows),
+        // 5 feature channels (colour frames) and 3 (gray frames) have their own instantiation with the channel loop unrolled
+        // [Also measured, same box: staging the blended tile (halo 2) in LDS so that every value is loaded once instead of ten
+        // times -- 0.05 ms per 1080p pair SLOWER (118 vs 111 us at level 0); the unrolled channel loop is worth 0.01 ms.]
+        const auto kern = planes == 5 ? k_assemble_skew<5> : planes == 3 ? k_assemble_skew<3> : k_assemble_skew<0>;
+        hipLaunchKernelGGL(kern, dim3((W + kTileJ - 1) / kTileJ, (r.y1 - r.y0 + kAsmRows - 1) / kAsmRows),
                            dim3(256), 0, h->stream, blend, imdt, phi, u, v, H, W, planes, alpha, omega, skew_idx(out),
                            (double2s*)out.phi, (double2s*)out.a1, (double2s*)out.b1, opt_imdx2, opt_imdy2,
                            deriv5_taps(), I, take_stamp(h), r.y0, r.y1);
