@@ -335,7 +335,7 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
             // noise estimate is about: its witnesses are taken here (LapGuard)
             PAPOF_TRY(warp_smooth_blend(h, f1, f2, u, v, im1s, B.blend, B.imdt, H, W, fc,
                                         lg && count > 0 && !B.gm ? lg->wit(lg->slot - 1) : nullptr,
-                                        count == 0 ? B.phi : nullptr));  // ... and phi of the level's initial flow
+                                        B.phi));  // ... and phi of the flow as it stands (Phase2, :295-331), by the way
         else
             PAPOF_TRY(smooth_hv_blend(h, warp, im1s, B.blend, B.imdt, H, W, fc));  // both passes + blend + imdt, fused
         // inner fixed-point iterations (src/OpticalFlow.cpp:290-506): after the first one, phi is taken at u + du and
@@ -344,7 +344,7 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
             const SorPlanes* prev = hh == 0 ? nullptr : &SP;
             // phi (Phase2): of the level's initial flow, and inside further inner iterations (at u + du), by its own kernel;
             // for every later outer iteration the previous iteration's update kernel has written it already
-            if ((count == 0 && !fold_warp) || hh > 0) {  // (fold_warp: warp_smooth_blend wrote the level's first phi)
+            if ((count == 0 && !fold_warp) || hh > 0) {  // (fold_warp: warp_smooth_blend has written phi of (u, v))
                 clk.phase(PAPOF_T_PHASE2_DERIVATIVES);
                 PAPOF_TRY(compute_phi(h, u, v, prev, B.phi, H, W));
             }
@@ -369,7 +369,9 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
             PAPOF_TRY(rc_solve);
         }
         // Phase6 (opened by the solver's end mark): u += du, v += dv and the re-warp of frame 2 (:513-521)
-        double* const phi_next = count + 1 < n_outer ? B.phi : nullptr;  // the next outer iteration's phi, fused in
+        // the next outer iteration's phi, fused in -- unless its warp_smooth_blend writes it (fold_warp: there it costs six
+        // row-contiguous loads per pixel in a fifth of the blocks; here, three scattered reads of the increment instead of one)
+        double* const phi_next = count + 1 < n_outer && !fold_warp ? B.phi : nullptr;
         // the re-warp after the LAST outer iteration of a level (:516) is read by nobody when the caller is flow_device (the
         // next level warps anew, the result is the bicubic warp of the originals): final_warp = false skips it
         const bool rewarp = !fold_warp && !B.bgx && (final_warp || count + 1 < n_outer || B.gm);
@@ -1165,14 +1167,14 @@ int flow_pass(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, i
         tm[PAPOF_T_PHASE3_PSIDATA] += kPsiShare * fused;
         tm[PAPOF_T_PHASE4_LINEARSYSTEM] = fused - kPsiShare * fused;
     }
-    {   // phi (Phase2_Derivatives, :295-331) has no kernel of its own on the default path any more: the update kernel writes
-        // the next iteration's (recorded under Phase6), the level's first smoothing kernel the initial one.  kPhiShare = phi's
-        // part of the update kernel -- 6 of its 14 memory streams, the square root and the division -- as a fixed
-        // apportioning of Phase6, not a measurement; a Phase2 measured by compute_phi() (inner iterations, strips) adds to it.
-        constexpr double kPhiShare = 0.4;
-        const double fused = tm[PAPOF_T_PHASE6_UPDATE];
+    {   // phi (Phase2_Derivatives, :295-331) has no kernel of its own on the default path any more: the warp-and-smooth kernel of
+        // every outer iteration (recorded under Phase1) writes it by the way.  kPhiShare = phi's part of that kernel -- its
+        // loads, the square root and the division in one block of five -- as a fixed apportioning of Phase1, not a
+        // measurement; a Phase2 measured by compute_phi() (inner iterations, the non-default branches) adds to it.
+        constexpr double kPhiShare = 0.04;
+        const double fused = tm[PAPOF_T_PHASE1_GENERATE];
         tm[PAPOF_T_PHASE2_DERIVATIVES] += kPhiShare * fused;
-        tm[PAPOF_T_PHASE6_UPDATE] = fused - kPhiShare * fused;
+        tm[PAPOF_T_PHASE1_GENERATE] = fused - kPhiShare * fused;
     }
     if (timing) std::memcpy(timing, tm, sizeof tm);
     if (op == kSeqNext) keep(slot1 ^ 1);  // the frame just solved against becomes frame 1 of the next push

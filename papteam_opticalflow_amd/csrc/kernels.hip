@@ -516,8 +516,8 @@ __global__ __launch_bounds__(256) void k_warp_smooth_blend(const double* __restr
         t += s2 * 0.6;
         blend[o] = t;
         imdt[o] = s2 - s1;
-        // phi of the level's INITIAL flow (the first outer iteration of a level; later ones get it from the update kernel):
-        // k_phi's expressions without an increment, by the blocks of channel 0 -- one launch fewer on the level's chain
+        // phi of the flow this outer iteration starts from: k_phi's expressions without an increment, by the blocks of channel
+        // 0 -- no launch of its own, and the update kernel is spared the scattered reads of its neighbours' increments
         if (phi_out != nullptr && blockIdx.z == 0) {
             const size_t q = (size_t)i * W + j;
             const double uc = u[q], vc = v[q];
@@ -695,7 +695,11 @@ struct SystemCell {
 // instruction issue, a third of it index arithmetic for the clamps).
 // PLANES > 0: the channel count as a compile-time constant -- the channel loop is unrolled, so the stencil loads of all
 // channels are in flight together instead of one channel's per memory round trip (same operations, same order).
-template <bool EDGE = true, int PLANES = 0>
+// FAST: the default branches, known at compile time -- Laplacian noise model without a consulted estimate (I.gm == I.lap ==
+// nullptr) and no increment of an earlier inner iteration (I.du == nullptr): no branch is left inside the channel loop, so
+// the stencil loads of all channels really are in flight together (the uniform branches cut the loop into basic blocks, each
+// with its own wait: five memory round trips per cell).
+template <bool EDGE = true, int PLANES = 0, bool FAST = false>
 __device__ __forceinline__ SystemCell assemble_cell(const double* __restrict__ blend, const double* __restrict__ imdt,
                                                     const double* __restrict__ phi, const double* __restrict__ u,
                                                     const double* __restrict__ v, int i, int j, int H, int W,
@@ -704,8 +708,8 @@ __device__ __forceinline__ SystemCell assemble_cell(const double* __restrict__ b
     const int planes = PLANES > 0 ? PLANES : planes_rt;
     const size_t np = (size_t)H * W, o = (size_t)i * W + j;
     double sxy = 0.0, sx2 = 0.0, sy2 = 0.0, stx = 0.0, sty = 0.0;
-    double du, dv;
-    increment_at(I, i, j, W, du, dv);
+    double du = 0.0, dv = 0.0;
+    if (!FAST) increment_at(I, i, j, W, du, dv);
     const auto channel = [&](int k) {
         const double* im = blend + k * np;
         double gx = 0.0, gy = 0.0;
@@ -723,10 +727,12 @@ __device__ __forceinline__ SystemCell assemble_cell(const double* __restrict__ b
         }
         const double gt = imdt[k * np + o];
         double t = gt;  // imdt + imdx*du + imdy*dv (src/OpticalFlow.cpp:384); du = dv = 0 in the first inner iteration
-        if (I.du != nullptr) t = gt + gx * du + gy * dv;
+        if (!FAST && I.du != nullptr) t = gt + gx * du + gy * dv;
         t *= t;
         double psi;
-        if (I.gm != nullptr) {  // :392-396 with GaussianMixture::Gaussian (src/NoiseModel.h:120-126).  The reference's PI there is
+        if (FAST) {
+            psi = 1 / (2 * sqrt(t + 0.001 * 0.001));
+        } else if (I.gm != nullptr) {  // :392-396 with GaussianMixture::Gaussian (src/NoiseModel.h:120-126).  The reference's PI there is
                                 // 3.1415927: Stochastic.h:19 defines it before NoiseModel.h's #ifndef (oracle/papof_oracle.c).
                                 // exp() is the device library's (<= 1 ulp, not glibc's bits): tolerance-checked branch.
             const double* g = I.gm;
@@ -833,7 +839,10 @@ __global__ void k_assemble(const double* __restrict__ blend, const double* __res
 // COMPUTED in row-major order (coalesced plane reads), staged in LDS, and WRITTEN in skew order -- for one skew
 // position (anti-diagonal) the 16 threads of a group store 16 neighbouring rows = 256 contiguous bytes per paired
 // plane -- instead of scattered 16-byte cells.
-constexpr int kTileJ = 16;
+#ifndef PAPOF_V_ASMCOLS
+#define PAPOF_V_ASMCOLS 16
+#endif
+constexpr int kTileJ = PAPOF_V_ASMCOLS;  // columns of the assembly kernel's tile = cells of one contiguous chunk it writes
 #ifndef PAPOF_V_ASMROWS
 #define PAPOF_V_ASMROWS 16  // same-box A/B (round 3, ms per 1080p pair): 62 rows 10.93-10.96, 31: 10.80, 24: 10.91, 16: 10.73-10.83, 12: 10.76-10.78, 8: 10.85-10.87
 #endif
@@ -841,7 +850,7 @@ constexpr int kAsmRows = PAPOF_V_ASMROWS;  // rows of the assembly kernel's tile
 struct double2s {
     double x, y;
 };
-template <int PLANES>
+template <int PLANES, bool FAST>
 __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict__ blend,
                                                        const double* __restrict__ imdt,
                                                        const double* __restrict__ phi, const double* __restrict__ u,
@@ -862,8 +871,8 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
         const int i = ib + r, j = j0 + jj;
         if (i < row1 && j < W) {
             const SystemCell s =
-                interior ? assemble_cell<false, PLANES>(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I)
-                         : assemble_cell<true, PLANES>(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I);
+                interior ? assemble_cell<false, PLANES, FAST>(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I)
+                         : assemble_cell<true, PLANES, FAST>(blend, imdt, phi, u, v, i, j, H, W, planes, alpha, omega, d, I);
             stage[0][r][jj] = s.phi;
             stage[1][r][jj] = s.xy;
             stage[2][r][jj] = s.a1;
@@ -1422,9 +1431,15 @@ int assemble_system(papof_handle* h, const double* blend, const double* imdt, co
     if (out.skew) {
         if (rc && (r.x0 != 0 || r.x1 != W)) return PAPOF_EINVAL;  // skew layout: whole rows only (strips of a plane)
         // 5 feature channels (colour frames) and 3 (gray frames) have their own instantiation with the channel loop unrolled
-        // [Also measured, same box: staging the blended tile (halo 2) in LDS so that every value is loaded once instead of ten
-        // times -- 0.05 ms per 1080p pair SLOWER (118 vs 111 us at level 0); the unrolled channel loop is worth 0.01 ms.]
-        const auto kern = planes == 5 ? k_assemble_skew<5> : planes == 3 ? k_assemble_skew<3> : k_assemble_skew<0>;
+        const bool fast = I.du == nullptr && I.gm == nullptr && I.lap == nullptr;  // the default branches (assemble_cell: FAST; 0.04 ms)
+        // Where its 109 us at level 0 go (variants of the kernel under rocprofv3, round 3): without the three plane stores 79 us
+        // (100 MB at the ~3.3 TB/s a plain fill reaches too), without the stencil loads 82, without sqrt / division 106 -- loads and
+        // stores, not arithmetic.  Not kept: tiles of 16x32 / 24x32 / 32x32 / 32x16 (512-byte chunks: 0 ... +0.12 ms per 1080p pair),
+        // non-temporal plane stores (+0.26 ms: the solver wants the planes where these stores leave them), the blended tile
+        // staged in LDS (+0.05 ms).
+        const auto kern = planes == 5   ? (fast ? k_assemble_skew<5, true> : k_assemble_skew<5, false>)
+                          : planes == 3 ? (fast ? k_assemble_skew<3, true> : k_assemble_skew<3, false>)
+                                        : k_assemble_skew<0, false>;
         hipLaunchKernelGGL(kern, dim3((W + kTileJ - 1) / kTileJ, (r.y1 - r.y0 + kAsmRows - 1) / kAsmRows),
                            dim3(256), 0, h->stream, blend, imdt, phi, u, v, H, W, planes, alpha, omega, skew_idx(out),
                            (double2s*)out.phi, (double2s*)out.a1, (double2s*)out.b1, opt_imdx2, opt_imdy2,
