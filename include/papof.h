@@ -84,7 +84,9 @@ typedef struct papof_params {
                                  no phase stamps at all -- what bench.py's device-resident headline runs with, as in round 1
                                  (the stamps cost <= 0.1 ms per 1080p call).
                               Phase5_SOR is the solver kernels' own duration in both cases.  Phase3_PsiData and
-                              Phase4_LinearSystem are ONE fused kernel here: its time is apportioned 30 : 70.          */
+                              Phase4_LinearSystem are ONE fused kernel here: its time is apportioned 30 : 70; on the default
+                              branches phi (Phase2_Derivatives) is written by the warp-and-smooth kernel of Phase1_Generate
+                              and reported as a fixed 4 % of it.                                                        */
     int interpolation;     /* PAPOF_INTERP_*  (0 = the reference's default)                                          */
     int noise_model;       /* PAPOF_NOISE_*   (0 = the reference's default)                                          */
 } papof_params;

@@ -294,9 +294,12 @@ struct LapGuard {
         int n = 0;
         for (int s = 0; s + 1 < slot; s++)  // the estimate behind the last iteration of a call is never consulted
             for (int c = 0; c < slot_channels[s]; c++) {
-                const bool witness = host_flags[lap_wit_word(s) + c] == epoch;
+                const unsigned w = host_flags[lap_wit_word(s) + c];
+                const bool witness = w == epoch || w == (epoch ^ kLapNone);  // a sample, or an exhaustive "no valid sample at all"
                 const bool all_zero = nz_known && host_flags[lap_nz_word(slot_level[s]) + c] != epoch;
                 n += !(witness || all_zero);
+                if (!(witness || all_zero) && std::getenv("PAPOF_LAP_TRACE"))
+                    std::fprintf(stderr, "[lap guard] no proof: slot %d of %d, level %d, channel %d\n", s, slot, slot_level[s], c);
             }
         return n;
     }
@@ -378,7 +381,9 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
         // witnesses of the Laplacian-noise guard (LapGuard); the bicubic branch has no sampled warp: it runs the exact pass
         // -- and taken by the next iteration's warp_smooth_blend where there is one on this level
         const bool wit_later = fold_warp && count + 1 < n_outer;
-        unsigned* const wit = lg && !B.gm && !B.bgx && !wit_later ? lg->wit(lg->slot) : nullptr;
+        // (a one-block level gets the exhaustive check of lap_small_check() behind its last update instead of samples)
+        const bool wit_small = fold_warp && !wit_later && lap_one_block_level(H, W);
+        unsigned* const wit = lg && !B.gm && !B.bgx && !wit_later && !wit_small ? lg->wit(lg->slot) : nullptr;
         if (out_u && out_v && count + 1 == n_outer) {  // the level's result goes straight to the caller's buffers
             PAPOF_TRY(update_warp_phi(h, SP, u, v, out_u, out_v, f1, f2, warp, phi_next, H, W, fc, rewarp, 0, -1, wit));
             u = out_u;
@@ -390,6 +395,8 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
         }
         if (B.bgx)  // interpolation == Bicubic: warpImageBicubicRef + threshold() on the feature planes
             PAPOF_TRY(bicubic_warp(h, f1, f2, B.bgx, B.bgy, B.bgxy, u, v, warp, H, W, fc, nullptr, true, true));
+        if (lg && lg->on && !B.gm && wit_small && lg->wit(lg->slot))
+            PAPOF_TRY(lap_small_check(h, f1, f2, u, v, H, W, fc, lg->wit(lg->slot)));
         if (lg && lg->on && !B.gm) {
             lg->slot_level.push_back(level);
             lg->slot_channels.push_back(fc);
@@ -1202,7 +1209,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     const papof_handle::Seq seq0 = h->seq;
     for (int pass = 0; pass < 2; pass++) {
         // a flag is set when it holds the number of the pass that wrote it: no clearing, nothing stale can be taken for a proof
-        if (++h->lap_epoch == 0u) {  // (2^32 passes later: start over on cleared flags)
+        if (++h->lap_epoch >= kLapNone) {  // (2^31 passes later: start over on cleared flags)
             PAPOF_HIP(hipMemsetAsync(h->lap_flags_dev, 0, kLapFlagWords * sizeof(unsigned), h->stream));
             h->lap_epoch = 1u;
         }

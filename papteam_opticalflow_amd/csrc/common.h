@@ -88,6 +88,7 @@ constexpr int kLapNzWords = 32 * 8, kLapMaxSlots = 1024;  // flags of the Laplac
 constexpr size_t kLapFlagWords = (size_t)kLapMaxSlots * 8 + kLapNzWords;
 inline size_t lap_wit_word(int slot) { return (size_t)(kLapMaxSlots - 1 - slot) * 8; }  // slots grow DOWNWARDS towards ...
 inline size_t lap_nz_word(int level) { return (size_t)kLapMaxSlots * 8 + (size_t)level * 8; }  // ... the non-zero flags
+constexpr unsigned kLapNone = 0x80000000u;  // witness word = pass number ^ kLapNone: a block that saw EVERY pixel found no valid sample
 constexpr int kSorMaxDepth = 32;  // largest software-pipeline depth (steps) of the exact-order SOR kernel
 constexpr int kBandRows = kLanes - 2;  // real rows per task: lanes 1..62; lanes 0 / 63 stand for the rows above / below
 
@@ -373,6 +374,9 @@ int assemble_system(papof_handle* h, const double* blend, const double* imdt, co
                     double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev, const Rect* rc = nullptr,
                     const double* gm = nullptr, const double* lap = nullptr);
 int lap_scratch_doubles();
+bool lap_one_block_level(int H, int W);  // k_warp_smooth_blend runs one block per channel: exhaustive check of the guard
+int lap_small_check(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H, int W,
+                    int C, unsigned* wit);  // the same check for the flow behind the last update of such a level
 int est_laplacian_noise(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H,
                         int W, int C, double* lap, double* scratch);  // the exact pass of the Laplacian-noise guard
 int gm_scratch_doubles();

@@ -421,7 +421,12 @@ __global__ __launch_bounds__(256) void k_warp_smooth_blend(const double* __restr
     // block compares 64 cells spread over the tile (their frame-1 values are fetched here, beside the gathers: no latency of
     // their own; halo cells are clamped copies of image pixels, warped as such: as good a sample as any).
     // Where the grid is large, one block in sixteen samples: thousands of stores to one word are not free.
-    const bool sampler = wit != nullptr && threadIdx.y == 0u &&
+    // A level that is ONE block per channel is checked EXHAUSTIVELY instead (every cell of the tile): on the few-pixel levels of a
+    // deep pyramid the flow can leave the image altogether -- every warped value is then frame 1's, no sample is valid and the
+    // estimate is the constant 0.001; the block that has seen every pixel says so (kLapNone), which is a proof as well.
+    const bool exhaustive = wit != nullptr && gridDim.x == 1u && gridDim.y == 1u;
+    bool ex_hit = false, ex_valid = false;
+    const bool sampler = wit != nullptr && !exhaustive && threadIdx.y == 0u &&
                          (gridDim.x * gridDim.y <= 256u || ((blockIdx.x + 5u * blockIdx.y) & 15u) == 0u);
     constexpr int kWitStride = (kWsRows + 4) * (BX + 4) / 64;
     const int wr = (int)(threadIdx.x * kWitStride) / (BX + 4), wc = (int)(threadIdx.x * kWitStride) - wr * (BX + 4);
@@ -486,9 +491,18 @@ __global__ __launch_bounds__(256) void k_warp_smooth_blend(const double* __restr
                 res += val[q][3] * (dx * dy);
             }
             raw[r][cc] = res;
+            if (exhaustive) {
+                const double d = fabs(p1[off[q]] - res);
+                ex_valid = ex_valid || (d > 0 && d < 1000000);
+                ex_hit = ex_hit || (d >= wit_thr && d < 1000000);
+            }
         }
     }
     __syncthreads();
+    if (exhaustive) {  // (block-uniform)
+        const int any_hit = __syncthreads_or(ex_hit ? 1 : 0), any_valid = __syncthreads_or(ex_valid ? 1 : 0);
+        if (tid == 0 && (any_hit || !any_valid)) wit[blockIdx.z] = any_hit ? mark : (mark ^ kLapNone);
+    }
     if (sampler) {
         const double d = fabs(own1 - raw[wr][wc]);
         const unsigned long long hits = __ballot(d >= wit_thr && d < 1000000);
@@ -1674,6 +1688,31 @@ static __global__ void k_lap_finish(const double* __restrict__ partial, int C, d
         n += partial[((size_t)b * kLapMaxC + k) * 2 + 1];
     }
     lap[k] = n == 0 ? 0.001 : s / n;
+}
+// The witness / no-valid-sample check of k_warp_smooth_blend's exhaustive mode for the LAST outer iteration of a one-block
+// level (nobody evaluates the warp at that flow): one block per channel over every pixel.
+static __global__ __launch_bounds__(256) void k_lap_small(const double* __restrict__ im1, const double* __restrict__ im2,
+                                                       const double* __restrict__ u, const double* __restrict__ v, int H,
+                                                       int W, unsigned* __restrict__ wit, double wit_thr, unsigned mark) {
+    const int np = H * W;
+    const double *p1 = im1 + (size_t)blockIdx.x * np, *p2 = im2 + (size_t)blockIdx.x * np;
+    bool hit = false, valid = false;
+    for (int o = threadIdx.x; o < np; o += 256) {
+        const int i = o / W, j = o - i * W;
+        const double d = fabs(p1[o] - warp_value(p1, p2, u[o], v[o], i, j, H, W));
+        valid = valid || (d > 0 && d < 1000000);
+        hit = hit || (d >= wit_thr && d < 1000000);
+    }
+    const int any_hit = __syncthreads_or(hit ? 1 : 0), any_valid = __syncthreads_or(valid ? 1 : 0);
+    if (threadIdx.x == 0 && (any_hit || !any_valid)) wit[blockIdx.x] = any_hit ? mark : (mark ^ kLapNone);
+}
+bool lap_one_block_level(int H, int W) { return H <= kWsRows && W <= BX; }
+int lap_small_check(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H, int W,
+                    int C, unsigned* wit) {
+    hipLaunchKernelGGL(k_lap_small, dim3(C), dim3(256), 0, h->stream, im1, im2, u, v, H, W, wit,
+                       2e-20 * (double)H * (double)W, h->lap_epoch);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
 }
 int lap_scratch_doubles() { return kLapBlocks * kLapMaxC * 2; }
 int est_laplacian_noise(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H,

@@ -711,8 +711,8 @@ def test_laplacian_noise_guard_never_reruns_ordinary_input(kind):
         elif kind == "black":
             z = np.zeros_like(a8)
             g.coarse2fine_flow_u8(z, z, levels)
-        elif kind == "deep":
-            g.coarse2fine_flow_u8(a8, b8, 12)
+        elif kind == "deep":  # 15 levels: the coarsest are a few pixels, the flow leaves them altogether in some iterations --
+            g.coarse2fine_flow_u8(a8, b8, 15)  # no valid sample at all, which the one-block levels' exhaustive check proves
         st = g.lap_guard_stats()
         if kind != "identical":
             assert st["reruns"] == 0 and st["exact_calls"] == 0 and st["exact_next"] is False, (kind, st)
