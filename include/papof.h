@@ -219,6 +219,13 @@ void papof_tiles_destroy(papof_tiles* t);
  * each.  Results are the same bits. */
 int papof_set_graph_mode(papof_handle* h, int on);
 
+/* Whether a call spreads over several streams of its own (the preparation beside the coarse levels' solves, PCIe copies beside
+ * kernels: the default, fastest for ONE call at a time) or stays on the handle's one stream (on = 0; also PAPOF_OVERLAP=0 when
+ * the handle is created).  With several handles in flight -- a collection of pairs, flow_collection() -- the other handles'
+ * calls fill the idle time and one stream per handle is faster (fewer hardware queues shared): 240x135 pairs on the
+ * reference schedule 3.2 -> 2.2 ms per pair with 16 in flight, 480x270 4.9 -> 3.4.  Results are the same bits. */
+int papof_set_stream_overlap(papof_handle* h, int on);
+
 /* Device memory helpers for callers without a HIP binding (bench.py, ctypes users). */
 int papof_dev_alloc(papof_handle* h, size_t bytes, void** out);
 int papof_dev_free(papof_handle* h, void* p);

@@ -120,10 +120,18 @@ _collection_handles = {}  # device -> handles kept between flow_collection calls
                           # of a handle cost tens of milliseconds to allocate)
 
 
-def flow_collection(frames, pyramidLevels, in_flight=4, device=None, on_pair=None, **solver):
+def collection_in_flight(height, width):
+    """Sequences flow_collection() keeps in flight by default: small frames leave the chip idle and their calls are bound by
+    the host's launch path, so many run side by side (measured on MI355X, reference schedule, tools/collection_probe.py:
+    240x135 and 480x270 peak at 16, 960x540 is flat from 4 to 16, 1920x1080 peaks at 4)."""
+    mpix = height * width / 1e6
+    return 16 if mpix <= 0.3 else (8 if mpix <= 1.0 else 4)
+
+
+def flow_collection(frames, pyramidLevels, in_flight=None, device=None, on_pair=None, **solver):
     """Flow of every consecutive pair of a frame list -- what the reference's TestSuite does with a collection
     (Code/Serial/TestSuite.py:69-81: frame n -> n+1 for 101 pairs) -- with `in_flight` sequences running concurrently
-    on one GPU: the list is cut into contiguous segments (overlapping by one frame), each pushed through its own
+    on one GPU (default: by frame size, collection_in_flight()): the list is cut into contiguous segments (overlapping by one frame), each pushed through its own
     FlowSequence (own handle, arena and streams) by its own host thread.  One pair alone leaves most of the chip idle
     while the coarse pyramid levels are solved; several in flight fill it (bench.py `concurrent_pairs`).
 
@@ -138,6 +146,9 @@ def flow_collection(frames, pyramidLevels, in_flight=4, device=None, on_pair=Non
     n_pairs = len(frames) - 1
     if n_pairs < 1:
         return None if on_pair else []
+    if in_flight is None:
+        h0, w0 = np.shape(frames[0])[:2]
+        in_flight = collection_in_flight(h0, w0)
     k = max(1, min(int(in_flight), n_pairs))
     bounds = [n_pairs * s // k for s in range(k + 1)]  # segment s computes pairs bounds[s] .. bounds[s+1]-1
     results, errors = [None] * n_pairs, []
@@ -146,6 +157,8 @@ def flow_collection(frames, pyramidLevels, in_flight=4, device=None, on_pair=Non
     pool = _collection_handles.setdefault(dev, [])
     while len(pool) < k:
         pool.append(Papof(dev))
+    for hnd in pool[:k]:  # several handles in flight fill each other's idle time: one stream per handle is faster then
+        hnd.set_stream_overlap(k == 1 and os.environ.get("PAPOF_OVERLAP", "1") != "0")
 
     def run(s):
         try:

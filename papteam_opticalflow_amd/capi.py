@@ -47,7 +47,7 @@ SYMBOLS = [
     "papof_seq_push", "papof_seq_push_u8", "papof_seq_push_device", "papof_tiles_grid", "papof_tiles_rect",
     "papof_tiles_halo_message", "papof_tiles_unique_id", "papof_tiles_create", "papof_tiles_create_local",
     "papof_tiles_flow_device", "papof_tiles_stats", "papof_tiles_destroy", "papof_flow_quantize16",
-    "papof_flow_dequantize16", "papof_flow_to_bgr", "papof_set_graph_mode", "papof_sor_plan", "papof_last_sor_stats", "papof_strip_plan", "papof_test_sor_strips",
+    "papof_flow_dequantize16", "papof_flow_to_bgr", "papof_set_graph_mode", "papof_set_stream_overlap", "papof_sor_plan", "papof_last_sor_stats", "papof_strip_plan", "papof_test_sor_strips",
     "papof_pyramid_levels_for_min_width", "papof_stage_smoothflow_ex", "papof_stage_est_gaussian_mixture",
     "papof_stage_bicubic_warp_ex", "papof_tiles_comm_info", "papof_host_alloc", "papof_host_free",
     "papof_last_sor_solves", "papof_bands_plan", "papof_lap_guard_stats",
@@ -111,6 +111,7 @@ def load():
     L.papof_flow_dequantize16.argtypes = [c_void_p, c_void_p, c_int, c_int, _D, _D]
     L.papof_flow_to_bgr.argtypes = [c_void_p, _D, _D, c_int, c_int, c_void_p]
     L.papof_set_graph_mode.argtypes = [c_void_p, c_int]
+    L.papof_set_stream_overlap.argtypes = [c_void_p, c_int]
     L.papof_dev_alloc.argtypes = [c_void_p, ctypes.c_size_t, ctypes.POINTER(c_void_p)]
     L.papof_dev_free.argtypes = [c_void_p, c_void_p]
     L.papof_dev_upload.argtypes = [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]
@@ -269,6 +270,10 @@ class Papof:
     def set_graph_mode(self, on=True):
         """hipGraph replay of whole calls (include/papof.h: papof_set_graph_mode)."""
         _chk(self.L.papof_set_graph_mode(self.h, 1 if on else 0), "papof_set_graph_mode")
+
+    def set_stream_overlap(self, on):
+        """several streams per call (default) or one (include/papof.h: papof_set_stream_overlap)."""
+        _chk(self.L.papof_set_stream_overlap(self.h, 1 if on else 0), "papof_set_stream_overlap")
 
     def close(self):
         if self.h:

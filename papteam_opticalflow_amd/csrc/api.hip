@@ -1529,6 +1529,12 @@ int papof_set_graph_mode(papof_handle* h, int on) {
     return PAPOF_OK;
 }
 
+int papof_set_stream_overlap(papof_handle* h, int on) {
+    if (!h) return PAPOF_EINVAL;
+    h->overlap_prep = on != 0;
+    return PAPOF_OK;
+}
+
 int papof_seq_reset(papof_handle* h) {
     if (!h) return PAPOF_EINVAL;
     h->seq.valid = false;

@@ -121,6 +121,36 @@ def test_collection_in_flight_equals_pairwise(gpu):
     assert len(one) == 1 and np.array_equal(one[0][1], got[0][1])
 
 
+def test_collection_default_in_flight_and_one_stream_per_handle(gpu):
+    """flow_collection() without `in_flight` picks the number of sequences by frame size (16 for the small frames of the
+    reference's own test matrix) and runs every handle on ONE stream (papof_set_stream_overlap(h, 0): with several handles in
+    flight the extra streams only share hardware queues).  Same bits as the pairwise call; the switch itself gives the same
+    bits on a single handle too."""
+    from papteam_opticalflow_amd import Papof, collection_in_flight, flow_collection
+    assert collection_in_flight(135, 240) == 16 and collection_in_flight(270, 480) == 16
+    assert collection_in_flight(540, 960) == 8 and collection_in_flight(1080, 1920) == 4
+    frames = _frames("240", 3)
+    video = [frames[i % 3] for i in range(20)]  # 19 pairs: 16 segments of one or two pairs
+    got = flow_collection(video, 3)
+    assert len(got) == 19
+    want = {}
+    for i, (t, vx, vy, w) in enumerate(got):
+        key = (i % 3, (i + 1) % 3)
+        if key not in want:
+            want[key] = gpu.coarse2fine_flow(_f64(video[i]), _f64(video[i + 1]), 3)
+        assert np.array_equal(vx, want[key][0]) and np.array_equal(vy, want[key][1]) and np.array_equal(w, want[key][2]), i
+    g = Papof(0)
+    try:
+        g.set_stream_overlap(False)
+        one = g.coarse2fine_flow(_f64(video[0]), _f64(video[1]), 3)
+        g.set_stream_overlap(True)
+        two = g.coarse2fine_flow(_f64(video[0]), _f64(video[1]), 3)
+    finally:
+        g.close()
+    for x, y, z in zip(one[:3], two[:3], want[(0, 1)][:3]):
+        assert np.array_equal(x, z) and np.array_equal(y, z)
+
+
 def test_graph_mode_replays_the_same_bits(gpu, oracle):
     """papof_set_graph_mode: the second call with the same arguments is captured into a hipGraph (both streams, every
     kernel / memset / copy), later calls replay it with one launch.  Eager, capturing and replaying calls must all
