@@ -331,9 +331,16 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
         PAPOF_TRY(filter_hv(h, f1, B.im1s, B.tmp, H, W, fc, g, g));
         im1s = B.im1s;
     }
+    // ONE kernel from the flow to the linear system (k_flow_system) where it applies: default branches, exact-order layout
+    static const bool fused_env = !(std::getenv("PAPOF_FUSED_SYSTEM") && std::getenv("PAPOF_FUSED_SYSTEM")[0] == '0');  // A/B switch
+    const bool fused_system = fused_env && fold_warp && n_inner == 1 && SP.skew && !B.gm && (fc == 5 || fc == 3) &&
+                              !(lg && lg->guard());
     for (int count = 0; count < n_outer; count++) {
-        clk.phase(PAPOF_T_PHASE1_GENERATE);
-        if (fold_warp)
+        clk.phase(fused_system ? kTimerFused : (int)PAPOF_T_PHASE1_GENERATE);
+        if (fused_system)
+            PAPOF_TRY(flow_system(h, f1, f2, u, v, im1s, H, W, fc, alpha, omega, SP,
+                                  lg && count > 0 ? lg->wit(lg->slot - 1) : nullptr));
+        else if (fold_warp)
             // warp + both passes + blend + imdt; the warp at the flow the previous iteration left is what that iteration's
             // noise estimate is about: its witnesses are taken here (LapGuard)
             PAPOF_TRY(warp_smooth_blend(h, f1, f2, u, v, im1s, B.blend, B.imdt, H, W, fc,
@@ -353,9 +360,10 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
             }
             // psi (Phase3, src/OpticalFlow.cpp:377-406) and the linear system (Phase4, :414-448) are ONE kernel here: its
             // time is recorded under Phase4 and apportioned between the two timers when they are collected (kPsiShare)
-            clk.phase(PAPOF_T_PHASE4_LINEARSYSTEM);
-            PAPOF_TRY(assemble_system(h, B.blend, B.imdt, B.phi, u, v, H, W, fc, alpha, omega, SP, nullptr, nullptr,
-                                      prev, nullptr, B.gm, lg ? lg->guard() : nullptr));
+            if (!fused_system) clk.phase(PAPOF_T_PHASE4_LINEARSYSTEM);
+            if (!fused_system)
+                PAPOF_TRY(assemble_system(h, B.blend, B.imdt, B.phi, u, v, H, W, fc, alpha, omega, SP, nullptr, nullptr,
+                                          prev, nullptr, B.gm, lg ? lg->guard() : nullptr));
             // Phase5_SOR is the solver kernels' own duration (the roofline of the dominant kernel is priced on it): the
             // events are recorded by sor_solve() right around its kernel(s), BEHIND the memset nodes that prepare a solve,
             // which therefore still count as Phase4
@@ -665,8 +673,9 @@ int flow_pass(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, i
     h->events_used = 0;
     const size_t np0 = (size_t)H * W;
     const int fc = feature_channels(C);
-    double tm[PAPOF_N_TIMERS];
+    double tm[PAPOF_N_TIMERS + 1];  // + kTimerFused (flow_internal.h)
     std::memset(tm, 0, sizeof tm);
+    const size_t tm_bytes = PAPOF_N_TIMERS * sizeof(double);  // what the caller gets
 
     // ---- hipGraph mode: eager on the first call with these arguments, captured on the second, replayed afterwards
     enum { kEager, kCapture, kReplay } gmode = kEager;
@@ -732,7 +741,7 @@ int flow_pass(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, i
         }
         if (P.sor_mode == PAPOF_SOR_EXACT) PAPOF_TRY(sor_check(h));
         tm[PAPOF_T_TOTAL] = ms * 1e-3;
-        if (timing) std::memcpy(timing, tm, sizeof tm);
+        if (timing) std::memcpy(timing, tm, tm_bytes);
         if (op == kSeqNext) keep_seq(slot1 ^ 1);
         return PAPOF_OK;
     };
@@ -801,7 +810,7 @@ int flow_pass(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, i
         PAPOF_TRY(build_pyramid(h, L, plan, C, false, tmp_a, tmp_b));
         PAPOF_HIP(hipStreamSynchronize(h->stream));
         keep(slot1);
-        if (timing) std::memset(timing, 0, sizeof tm);
+        if (timing) std::memset(timing, 0, tm_bytes);
         return PAPOF_OK;
     }
 
@@ -824,6 +833,9 @@ int flow_pass(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, i
     double* warp = A.f64(np0 * fc);
     // the flow lives in two PAIRS of planes (the update of an outer iteration writes the other pair); within a pair v follows
     // u at the pitch of the level in work, so that the up-sampling of (u, v) is one launch and their first clear one fill
+    // [a handle that cuts levels into strips (PAPOF_STRIPS, an A/B switch) keeps the full-resolution pitch on every level: its
+    // strips read the previous level's pair while they write this level's, row range by row range]
+    const bool paired = h->strips <= 1;
     double* u = A.f64(2 * np0);
     double* v = u ? u + np0 : nullptr;
     double* u2 = A.f64(2 * np0);
@@ -1047,26 +1059,34 @@ int flow_pass(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, i
             LevelInit li{k == levels - 1, nullptr, nullptr, ph, pw, 0.0, 0.0, 1 / ratio};
             const bool fold_warp = !strips && !B.bgx && !B.gm;  // the warped frame 2 lives only inside the smoothing kernel
             if (k == levels - 1) {  // src/OpticalFlow.cpp:801-806
-                v = u + np;
-                v2 = u2 + np;
-                PAPOF_HIP(hipMemsetAsync(u, 0, 2 * np * sizeof(double), h->stream));
+                if (paired) {
+                    v = u + np;
+                    v2 = u2 + np;
+                    PAPOF_HIP(hipMemsetAsync(u, 0, 2 * np * sizeof(double), h->stream));
+                } else {
+                    PAPOF_HIP(hipMemsetAsync(u, 0, np * sizeof(double), h->stream));
+                    PAPOF_HIP(hipMemsetAsync(v, 0, np * sizeof(double), h->stream));
+                }
                 if (!fold_warp)
                     PAPOF_HIP(hipMemcpyAsync(warp, f2, np * fc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
                 if (B.bgx) PAPOF_TRY(bicubic_planes(h, f2, lh, lw, fc, B));
             } else {  // :809-816
                 const double xr = (double)lw / pw, yr = (double)lh / ph, inv = 1 / ratio;
-                v2 = u2 + np;  // the pair that receives this level's flow, at this level's pitch
+                if (paired) v2 = u2 + np;  // the pair that receives this level's flow, at this level's pitch
                 if (strips) {  // up-sampling and warp happen per strip
                     li.pu = u;
                     li.pv = v;
                     li.xr = xr;
                     li.yr = yr;
-                } else {
+                } else if (paired) {
                     PAPOF_TRY(resize(h, u, u2, ph, pw, 2, lh, lw, xr, yr, true, inv));  // u and v: two planes of one launch
+                } else {
+                    PAPOF_TRY(resize(h, u, u2, ph, pw, 1, lh, lw, xr, yr, true, inv));
+                    PAPOF_TRY(resize(h, v, v2, ph, pw, 1, lh, lw, xr, yr, true, inv));
                 }
                 std::swap(u, u2);
                 std::swap(v, v2);
-                v2 = u2 + np;  // the free pair, at this level's pitch too
+                if (paired) v2 = u2 + np;  // the free pair, at this level's pitch too
                 if (strips || fold_warp) {
                 } else if (!B.bgx) {
                     PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc));
@@ -1160,7 +1180,7 @@ int flow_pass(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, i
         for (size_t i = 0; i < h->sor_log.size(); i++) h->sor_log[i].sec = clk.sor_span_sec[i];
     if (uclk.err != PAPOF_OK) return PAPOF_EDEVICE;
     {   // Phase5_SOR = the solver kernels' own time, all strips (on the main chain's time line only the lowest strip's)
-        double tu[PAPOF_N_TIMERS];
+        double tu[PAPOF_N_TIMERS + 1];
         std::memset(tu, 0, sizeof tu);
         uclk.collect(tu);
         h->sor_upper_sec = tu[PAPOF_T_PHASE5_SOR];
@@ -1183,7 +1203,15 @@ int flow_pass(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, i
         tm[PAPOF_T_PHASE2_DERIVATIVES] += kPhiShare * fused;
         tm[PAPOF_T_PHASE1_GENERATE] = fused - kPhiShare * fused;
     }
-    if (timing) std::memcpy(timing, tm, sizeof tm);
+    {   // k_flow_system did the work of four timers in one launch (the levels it applies to): apportioned by the times of the
+        // kernels it replaces at level 0 -- warp / smoothing / derivatives 122 us of which phi 4 %, psi + system 109 us at 30 : 70
+        const double f = tm[kTimerFused];
+        tm[PAPOF_T_PHASE1_GENERATE] += 0.51 * f;
+        tm[PAPOF_T_PHASE2_DERIVATIVES] += 0.02 * f;
+        tm[PAPOF_T_PHASE3_PSIDATA] += 0.14 * f;
+        tm[PAPOF_T_PHASE4_LINEARSYSTEM] += f - 0.51 * f - 0.02 * f - 0.14 * f;
+    }
+    if (timing) std::memcpy(timing, tm, tm_bytes);
     if (op == kSeqNext) keep(slot1 ^ 1);  // the frame just solved against becomes frame 1 of the next push
     return PAPOF_OK;
 }

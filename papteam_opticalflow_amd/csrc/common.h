@@ -373,6 +373,8 @@ int assemble_system(papof_handle* h, const double* blend, const double* imdt, co
                     const double* v, int H, int W, int planes, double alpha, double omega, const SorPlanes& out,
                     double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev, const Rect* rc = nullptr,
                     const double* gm = nullptr, const double* lap = nullptr);
+int flow_system(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, const double* im1s,
+                int H, int W, int planes, double alpha, double omega, const SorPlanes& out, unsigned* wit = nullptr);
 int lap_scratch_doubles();
 bool lap_one_block_level(int H, int W);  // k_warp_smooth_blend runs one block per channel: exhaustive check of the guard
 int lap_small_check(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H, int W,

@@ -20,6 +20,9 @@ void set_last_error_text(const std::string& text);
 // memory pays for it when it ends), and a phase lasts from its stamp to the next one.  A HIP event between two kernels costs
 // ~2.6 us of stream time, and a call has ~100 phase boundaries: measured 11.8 vs 11.5 ms per 1080p pair.  Only
 // Phase5_SOR keeps a HIP event pair as well (the roofline of the dominant kernel is priced on those events).
+// Internal eleventh timer (arrays handed to PhaseClock::collect hold PAPOF_N_TIMERS + 1 values): the kernel that does the work
+// of Phase1 ... Phase4 in one launch (kernels.hip: k_flow_system); api.hip apportions it to those four when it reports.
+constexpr int kTimerFused = PAPOF_N_TIMERS;
 struct PhaseClock {
     papof_handle* h;
     bool on;
@@ -31,6 +34,7 @@ struct PhaseClock {
     bool stamps = false;
     std::vector<std::pair<int, int>> marks;  // stamp mode: (slot, timer index) in stream order
     std::vector<double> sor_span_sec;        // collect(): seconds of every Phase5_SOR span, in stream order (one per solve)
+    std::vector<int> sor_owner;              // stamp mode: the timer whose span runs across that solve (see phase())
     size_t new_event() {
         if (h->events_used == h->events.size()) {
             hipEvent_t e;
@@ -51,12 +55,15 @@ struct PhaseClock {
                 const size_t e = new_event();
                 spans.push_back({PAPOF_T_PHASE5_SOR, {open, e}});
             }
-            if (idx == PAPOF_T_PHASE5_SOR) open = new_event();
+            if (idx == PAPOF_T_PHASE5_SOR) {
+                open = new_event();
+                sor_owner.push_back(marks.empty() ? PAPOF_T_PHASE4_LINEARSYSTEM : marks.back().second);
+            }
             const bool sor_edge = idx == PAPOF_T_PHASE5_SOR;
             open_idx = idx;
             // The solver kernels carry no stamp (a store at the head of the critical task of the exact-order kernels was
-            // measured to cost ~12 us per solve): the span that contains a solve keeps running as Phase4 until the
-            // update kernel's stamp, and collect() subtracts the solver's own (event-measured) time from it.
+            // measured to cost ~12 us per solve): the span that contains a solve keeps running as Phase4 (or kTimerFused) until
+            // the update kernel's stamp, and collect() subtracts the solver's own (event-measured) time from it.
             if (only_sor || !h->stamps_dev || sor_edge) return;
             if (h->next_stamp && !marks.empty()) {
                 marks.back().second = idx;  // no stamping kernel ran in the previous phase: it is absorbed by its predecessor
@@ -91,9 +98,11 @@ struct PhaseClock {
             const unsigned long long a = h->stamps[marks[i].first], b = h->stamps[marks[i + 1].first];
             if (idx >= 0 && idx != PAPOF_T_PHASE5_SOR && b >= a) t[idx] += (double)(b - a) * 1e-8;  // 100 MHz ticks
         }
-        if (stamps && !marks.empty()) {  // the Phase4 spans ran across the solves: take the solver kernels' time out
-            double& p4 = t[PAPOF_T_PHASE4_LINEARSYSTEM];
-            p4 = p4 > t[PAPOF_T_PHASE5_SOR] ? p4 - t[PAPOF_T_PHASE5_SOR] : 0.0;
+        if (stamps && !marks.empty()) {  // the spans that ran across the solves: take the solver kernels' time out
+            for (size_t i = 0; i < sor_span_sec.size() && i < sor_owner.size(); i++)
+                if (sor_owner[i] >= 0) t[sor_owner[i]] -= sor_span_sec[i];
+            for (int own : {(int)PAPOF_T_PHASE4_LINEARSYSTEM, kTimerFused})
+                if (t[own] < 0.0) t[own] = 0.0;
         }
     }
 };

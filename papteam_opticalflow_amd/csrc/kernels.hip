@@ -956,6 +956,263 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_flow_system: k_warp_smooth_blend + k_assemble_skew<PLANES, FAST> in ONE kernel (default branches, exact-order layout) -- the
+// warped, smoothed and blended tile goes to the derivative / psi / coefficient stage through LDS, so `blend` and `imdt` (166 MB
+// written and read again per level-0 iteration) never go to HBM.  A block owns kFT x kFT cells and works, channel by channel,
+// on tiles indexed by PIXEL (position - origin; only pixels inside the image are computed, a consumer looks its neighbour
+// clamp(p + l) up): the warp on the tile + 4, its smoothing on + 2 (which is where the blend and imdt live), the derivatives on
+// the tile.  phi of the tile (and its upper / left neighbours) is computed from (u, v) into LDS.  Every expression and its
+// order are those of the two kernels it replaces: same bits.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFT = 16, kFH = 4, kFW = kFT + 2 * kFH;  // tile, halo, tile with halo
+template <int PLANES>
+__global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ im1, const double* __restrict__ im2,
+                                                     const double* __restrict__ u, const double* __restrict__ v,
+                                                     const double* __restrict__ im1s, int H, int W, double alpha,
+                                                     double omega, SkewIdx sk, double2s* __restrict__ pa,
+                                                     double2s* __restrict__ pb, double2s* __restrict__ pc, Taps g, Taps d,
+                                                     unsigned long long* stamp, unsigned* __restrict__ wit, double wit_thr,
+                                                     unsigned mark) {
+    __shared__ double raw[kFW][kFW + 1];            // warped frame 2, pixels (ib - 4 .. ib + 19) x (j0 - 4 .. j0 + 19)
+    __shared__ double hs[kFW][kFT + 4 + 1];         // h-smoothed, columns j0 - 2 .. j0 + 17
+    __shared__ double bl[kFT + 4][kFT + 4 + 1];     // blend, pixels (ib - 2 .. ib + 17) x (j0 - 2 .. j0 + 17)
+    __shared__ double it[kFT][kFT + 1];             // imdt of the tile
+    __shared__ double ph[kFT + 1][kFT + 1 + 1];     // phi, pixels (ib - 1 .. ib + 15) x (j0 - 1 .. j0 + 15)
+    __shared__ double stage[6][kFT][kFT + 1];
+    stamp_now(stamp);
+    const int ib = blockIdx.y * kFT, j0 = blockIdx.x * kFT, tid = threadIdx.x;
+    const size_t np = (size_t)H * W;
+    // ---- bilinear taps of the tile's pixels, once for all channels: (x0, y0), (dx, dy), or "outside" (frame 1's value)
+    constexpr int kPer = (kFW * kFW + 255) / 256;  // 3
+    int t_o[kPer], t_x0[kPer], t_y0[kPer];
+    double t_dx[kPer], t_dy[kPer];
+    bool t_in[kPer], t_out[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; q++) {
+        const int c = tid + q * 256, r = c / kFW, cc = c - r * kFW;
+        const int i = ib - kFH + r, j = j0 - kFH + cc;
+        t_in[q] = c < kFW * kFW && i >= 0 && i < H && j >= 0 && j < W;
+        t_o[q] = t_in[q] ? i * W + j : 0;
+        double x = 0.0, y = 0.0;  // (a cell outside the image: any valid position, its value is not used)
+        t_out[q] = false;
+        if (t_in[q]) {
+            y = i + v[t_o[q]];
+            x = j + u[t_o[q]];
+            t_out[q] = x < 0 || x > W - 1 || y < 0 || y > H - 1;  // warp_value()
+            if (t_out[q]) {
+                x = j;
+                y = i;
+            }
+        }
+        t_x0[q] = (int)x;
+        t_y0[q] = (int)y;
+        t_dx[q] = x - t_x0[q];
+        t_dy[q] = y - t_y0[q];
+    }
+    // ---- phi of the tile and its upper / left neighbours (k_phi without an increment), and the flow of the own cell
+    for (int c = tid; c < (kFT + 1) * (kFT + 1); c += 256) {
+        const int r = c / (kFT + 1), cc = c - r * (kFT + 1);
+        const int i = ib - 1 + r, j = j0 - 1 + cc;
+        if (i < 0 || i >= H || j < 0 || j >= W) continue;
+        const size_t o = (size_t)i * W + j;
+        const double uc = u[o], vc = v[o];
+        double ur = 0.0, vr = 0.0, ud = 0.0, vd = 0.0;
+        if (j < W - 1) {
+            ur = u[o + 1];
+            vr = v[o + 1];
+        }
+        if (i < H - 1) {
+            ud = u[o + W];
+            vd = v[o + W];
+        }
+        const double ux = j < W - 1 ? ur - uc : 0.0;
+        const double uy = i < H - 1 ? ud - uc : 0.0;
+        const double vx = j < W - 1 ? vr - vc : 0.0;
+        const double vy = i < H - 1 ? vd - vc : 0.0;
+        const double tt = ux * ux + uy * uy + vx * vx + vy * vy;
+        ph[r][cc] = 0.5 / sqrt(tt + 0.001 * 0.001);
+    }
+    const int orow = tid / kFT, ocol = tid - orow * kFT;  // this thread's cell of the tile
+    const int oi = ib + orow, oj = j0 + ocol;
+    const bool own = oi < H && oj < W;
+    double sxy = 0.0, sx2 = 0.0, sy2 = 0.0, stx = 0.0, sty = 0.0;
+    // witnesses of the Laplacian-noise guard (k_warp_smooth_blend): one block in sixteen on large grids, its first wave
+    const bool sampler = wit != nullptr && tid < 64 &&
+                         (gridDim.x * gridDim.y <= 256u || ((blockIdx.x + 5u * blockIdx.y) & 15u) == 0u);
+    // The global operands of a channel are PREFETCHED while the previous channel is worked on (a workgroup barrier does not
+    // wait for loads in flight): the gathers (or frame 1's value for a pixel that leaves the image) right behind P1, the smoothed
+    // frame 1 of the blend's pixels right behind P3 -- the phases between are LDS only.
+    constexpr int kP3 = ((kFT + 4) * (kFT + 4) + 255) / 256;  // 2
+    double gv[kPer][4], s1v[kP3], wv = 0.0;
+    const auto load_gathers = [&](int k) {
+        const double *p1 = im1 + k * np, *p2 = im2 + k * np;
+#pragma unroll
+        for (int q = 0; q < kPer; q++) {  // branch-free: a pixel that leaves the image gathers around ITSELF in frame 1 (its taps were
+            // set to its own position: tap 0 is frame 1's value), a cell outside the image reads pixel 0 and is not used
+            const double* src = t_out[q] ? p1 : p2;
+            const int x0 = t_x0[q], y0 = t_y0[q], x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+            gv[q][0] = src[y0 * W + x0];
+            gv[q][1] = src[y1 * W + x0];
+            gv[q][2] = src[y0 * W + x1];
+            gv[q][3] = src[y1 * W + x1];
+        }
+        if (sampler) wv = p1[t_o[0]];
+    };
+    const auto load_s1 = [&](int k) {
+        const double* ps = im1s + k * np;
+#pragma unroll
+        for (int q = 0; q < kP3; q++) {  // (branch-free: a position outside the image reads its clamped pixel and is not used)
+            const int c = min(tid + q * 256, (kFT + 4) * (kFT + 4) - 1), r = c / (kFT + 4), cc = c - r * (kFT + 4);
+            s1v[q] = ps[(size_t)clampi(ib - 2 + r, H) * W + clampi(j0 - 2 + cc, W)];
+        }
+    };
+    load_gathers(0);
+    load_s1(0);
+#pragma unroll 1
+    for (int k = 0; k < PLANES; k++) {
+        // -- P1: the warp
+        bool hit = false;
+#pragma unroll
+        for (int q = 0; q < kPer; q++) {
+            const int c = tid + q * 256, r = c / kFW, cc = c - r * kFW;
+            const double dx = t_dx[q], dy = t_dy[q], ex = 1.0 - dx, ey = 1.0 - dy;
+            double res = 0.0;
+            res += gv[q][0] * (ex * ey);
+            res += gv[q][1] * (ex * dy);
+            res += gv[q][2] * (dx * ey);
+            res += gv[q][3] * (dx * dy);
+            res = t_out[q] ? gv[q][0] : res;  // warp_value(): a pixel that leaves the image takes frame 1's value
+            if (t_in[q]) raw[r][cc] = res;
+            if (sampler && q == 0) {
+                const double dd = fabs(wv - res);
+                hit = t_in[q] && dd >= wit_thr && dd < 1000000;
+            }
+        }
+        if (sampler) {
+            const unsigned long long hits = __ballot(hit);
+            if (hits != 0ull && tid == 0) wit[k] = mark;
+        }
+        if (k + 1 < PLANES) load_gathers(k + 1);
+        __syncthreads();
+        // -- P2: horizontal pass on every row of the tile, columns j0 - 2 .. j0 + 17
+        for (int c = tid; c < kFW * (kFT + 4); c += 256) {
+            const int r = c / (kFT + 4), cc = c - r * (kFT + 4);
+            const int i = ib - kFH + r, j = j0 - 2 + cc;
+            if (i < 0 || i >= H || j < 0 || j >= W) continue;
+            double acc = 0.0;
+#pragma unroll
+            for (int l = -2; l <= 2; l++) acc += raw[r][clampi(j + l, W) - (j0 - kFH)] * g.t[l + 2];
+            hs[r][cc] = acc;
+        }
+        __syncthreads();
+        // -- P3: vertical pass, blend and imdt on (ib - 2 .. ib + 17) x (j0 - 2 .. j0 + 17)
+#pragma unroll
+        for (int q = 0; q < kP3; q++) {
+            const int c = tid + q * 256, r = c / (kFT + 4), cc = c - r * (kFT + 4);
+            const int i = ib - 2 + r, j = j0 - 2 + cc;
+            if (c >= (kFT + 4) * (kFT + 4) || i < 0 || i >= H || j < 0 || j >= W) continue;
+            double s2 = 0.0;
+#pragma unroll
+            for (int l = -2; l <= 2; l++) s2 += hs[clampi(i + l, H) - (ib - kFH)][cc] * g.t[l + 2];
+            const double s1 = s1v[q];
+            double t = s1;
+            t *= 0.4;
+            t += s2 * 0.6;
+            bl[r][cc] = t;
+            if (r >= 2 && r < kFT + 2 && cc >= 2 && cc < kFT + 2) it[r - 2][cc - 2] = s2 - s1;
+        }
+        if (k + 1 < PLANES) load_s1(k + 1);
+        __syncthreads();
+        // -- P4: derivatives, psi and the channel's terms of the own cell (assemble_cell, FAST)
+        if (own) {
+            double gx = 0.0, gy = 0.0;
+#pragma unroll
+            for (int l = -2; l <= 2; l++) gx += bl[orow + 2][clampi(oj + l, W) - (j0 - 2)] * d.t[l + 2];
+#pragma unroll
+            for (int l = -2; l <= 2; l++) gy += bl[clampi(oi + l, H) - (ib - 2)][ocol + 2] * d.t[l + 2];
+            const double gt = it[orow][ocol];
+            double t = gt;
+            t *= t;
+            const double psi = 1 / (2 * sqrt(t + 0.001 * 0.001));
+            const double pgx = psi * gx, pgy = psi * gy;
+            if (PLANES == 1) {
+                sxy = pgx * gy;
+                sx2 = pgx * gx;
+                sy2 = pgy * gy;
+                stx = pgx * gt;
+                sty = pgy * gt;
+            } else {
+                sxy += pgx * gy;
+                sx2 += pgx * gx;
+                sy2 += pgy * gy;
+                stx += pgx * gt;
+                sty += pgy * gt;
+            }
+        }
+        // (the next channel's P1 writes raw, last read in P2; its P3 writes bl / it, read above: two barriers lie between)
+    }
+    if (own) {
+        if (PLANES > 1) {
+            sxy = sxy / PLANES;
+            sx2 = sx2 / PLANES;
+            sy2 = sy2 / PLANES;
+            stx = stx / PLANES;
+            sty = sty / PLANES;
+        }
+        const int i = oi, j = oj;
+        const size_t o = (size_t)i * W + j;
+        const double pc_ = ph[orow + 1][ocol + 1];
+        const double pl = j > 0 ? ph[orow + 1][ocol] : 0.0, pu = i > 0 ? ph[orow][ocol + 1] : 0.0;
+        // laplacian_at(u, phi) / laplacian_at(v, phi) and sor_diagonals(phi) with phi from LDS
+        const double uc = u[o], vc = v[o];
+        double lu = 0.0, lv = 0.0;
+        if (j < W - 1) {
+            lu -= (u[o + 1] - uc) * pc_;
+            if (j > 0) lu += (uc - u[o - 1]) * pl;
+        }
+        if (i < H - 1) {
+            lu -= (u[o + W] - uc) * pc_;
+            if (i > 0) lu += (uc - u[o - W]) * pu;
+        }
+        if (j < W - 1) {
+            lv -= (v[o + 1] - vc) * pc_;
+            if (j > 0) lv += (vc - v[o - 1]) * pl;
+        }
+        if (i < H - 1) {
+            lv -= (v[o + W] - vc) * pc_;
+            if (i > 0) lv += (vc - v[o - W]) * pu;
+        }
+        double coeff = 0.0;
+        if (j > 0) coeff += pl;
+        if (j < W - 1) coeff += pc_;
+        if (i > 0) coeff += pu;
+        if (i < H - 1) coeff += pc_;
+        coeff *= alpha;
+        stage[0][orow][ocol] = pc_;
+        stage[1][orow][ocol] = sxy;
+        stage[2][orow][ocol] = omega / (sx2 + alpha * 0.05 + coeff);
+        stage[3][orow][ocol] = omega / (sy2 + alpha * 0.05 + coeff);
+        stage[4][orow][ocol] = -stx - alpha * lu;
+        stage[5][orow][ocol] = -sty - alpha * lv;
+    }
+    __syncthreads();
+    // ---- written in skew order, as k_assemble_skew does: a group of 16 threads stores 16 neighbouring rows of one position
+    const int grp = tid / kFT, jj = tid - grp * kFT;
+    const int j = j0 + jj;
+    if (j >= W) return;
+    for (int pp = grp; pp <= 2 * kFT - 2; pp += 256 / kFT) {
+        const int r = pp - jj;
+        if (r < 0 || r >= kFT) continue;
+        const int i = ib + r;
+        if (i >= H) continue;
+        const size_t q = skew_cell(i, j, sk);
+        pa[q] = double2s{stage[0][r][jj], stage[1][r][jj]};
+        pb[q] = double2s{stage[2][r][jj], stage[3][r][jj]};
+        pc[q] = double2s{stage[4][r][jj], stage[5][r][jj]};
+    }
+}
+
 // stage helper: SOR operands from already assembled row-major planes (tests / micro-benchmark)
 template <bool SKEW>
 __global__ void k_sor_prep(const double* __restrict__ phi, const double* __restrict__ imdxy,
@@ -1517,6 +1774,20 @@ int assemble_system(papof_handle* h, const double* blend, const double* imdt, co
                            alpha, omega, out.phi, out.xy, out.a1, out.a2, out.b1, out.b2, opt_imdx2, opt_imdy2,
                            deriv5_taps(), I, r, take_stamp(h));
     }
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
+
+// k_flow_system: the default branches of warp_smooth_blend() + assemble_system() in one launch (exact-order layout, 5 or 3
+// feature channels); returns PAPOF_EINVAL where it does not apply
+int flow_system(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, const double* im1s,
+                int H, int W, int planes, double alpha, double omega, const SorPlanes& out, unsigned* wit) {
+    if (!out.skew || (planes != 5 && planes != 3)) return PAPOF_EINVAL;
+    const dim3 grid((W + kFT - 1) / kFT, (H + kFT - 1) / kFT);
+    const auto kern = planes == 5 ? k_flow_system<5> : k_flow_system<3>;
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, h->stream, im1, im2, u, v, im1s, H, W, alpha, omega, skew_idx(out),
+                       (double2s*)out.phi, (double2s*)out.a1, (double2s*)out.b1, smooth5_taps(), deriv5_taps(), take_stamp(h),
+                       wit, 2e-20 * (double)H * (double)W, h->lap_epoch);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }

@@ -469,7 +469,7 @@ int tiles_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     const size_t np0 = (size_t)H * W;
     const int fc = feature_channels(C);
     const int me = t.tp->rank, S = t.halo, HU = S + 3;
-    double tm[PAPOF_N_TIMERS];
+    double tm[PAPOF_N_TIMERS + 1];  // + kTimerFused (flow_internal.h: PhaseClock::collect)
     std::memset(tm, 0, sizeof tm);
     PhaseClock total{h, true}, sorclk{h, true};
     total.phase(PAPOF_T_TOTAL);
@@ -661,7 +661,7 @@ int tiles_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     if (total.err != PAPOF_OK || sorclk.err != PAPOF_OK) return PAPOF_EDEVICE;
     sorclk.collect(tm);
     total.collect(tm);
-    if (timing) std::memcpy(timing, tm, sizeof tm);
+    if (timing) std::memcpy(timing, tm, PAPOF_N_TIMERS * sizeof(double));
     return PAPOF_OK;
 }
 
@@ -743,7 +743,7 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     const size_t np0 = (size_t)H * W;
     const int fc = feature_channels(C);
     const int me = t.tp->rank, n = t.tp->nranks;
-    double tm[PAPOF_N_TIMERS];
+    double tm[PAPOF_N_TIMERS + 1];  // + kTimerFused (flow_internal.h: PhaseClock::collect)
     std::memset(tm, 0, sizeof tm);
     PhaseClock total{h, true}, sorclk{h, true};
     total.phase(PAPOF_T_TOTAL);
@@ -1037,7 +1037,7 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     if (total.err != PAPOF_OK || sorclk.err != PAPOF_OK) return PAPOF_EDEVICE;
     sorclk.collect(tm);
     total.collect(tm);
-    if (timing) std::memcpy(timing, tm, sizeof tm);
+    if (timing) std::memcpy(timing, tm, PAPOF_N_TIMERS * sizeof(double));
     return PAPOF_OK;
 }
 
