@@ -966,6 +966,7 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
 // order are those of the two kernels it replaces: same bits.
 // ------------------------------------------------------------------------------------------------
 constexpr int kFT = 16, kFH = 4, kFW = kFT + 2 * kFH;  // tile, halo, tile with halo
+// [163 registers: three workgroups per CU; forcing four or five waves per SIMD spills: 11.2 / 12.8 ms per 1080p pair against 10.35]
 template <int PLANES>
 __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ im1, const double* __restrict__ im2,
                                                      const double* __restrict__ u, const double* __restrict__ v,
