@@ -86,7 +86,8 @@ typedef struct papof_params {
                               Phase5_SOR is the solver kernels' own duration in both cases.  Phase3_PsiData and
                               Phase4_LinearSystem are ONE fused kernel here: its time is apportioned 30 : 70; on the default
                               branches phi (Phase2_Derivatives) is written by the warp-and-smooth kernel of Phase1_Generate
-                              and reported as a fixed 4 % of it.                                                        */
+                              and reported as a fixed 4 % of it; where ONE kernel does Phase1 ... Phase4 (k_flow_system: default
+                              branches, one GPU) its time is apportioned 51 : 2 : 14 : 33.                              */
     int interpolation;     /* PAPOF_INTERP_*  (0 = the reference's default)                                          */
     int noise_model;       /* PAPOF_NOISE_*   (0 = the reference's default)                                          */
 } papof_params;
