@@ -332,7 +332,8 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
         im1s = B.im1s;
     }
     // ONE kernel from the flow to the linear system (k_flow_system) where it applies: default branches, exact-order layout
-    static const bool fused_env = !(std::getenv("PAPOF_FUSED_SYSTEM") && std::getenv("PAPOF_FUSED_SYSTEM")[0] == '0');  // A/B switch
+    const char* const fused_sw = std::getenv("PAPOF_FUSED_SYSTEM");  // A/B switch, and how the tests reach the pair of kernels
+    const bool fused_env = !(fused_sw && fused_sw[0] == '0');
     const bool fused_system = fused_env && fold_warp && n_inner == 1 && SP.skew && !B.gm && (fc == 5 || fc == 3) &&
                               !(lg && lg->guard());
     for (int count = 0; count < n_outer; count++) {

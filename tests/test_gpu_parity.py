@@ -621,6 +621,23 @@ def test_laplacian_noise_guard_tripping_case(gpu, oracle):
         assert np.array_equal(cases.subsample(a), w), "stage_lapguard/%s: max-abs %.3e" % (k, np.abs(cases.subsample(a) - w).max())
 
 
+@pytest.mark.parametrize("h,w,levels", [(135, 240, 3), (101, 173, 3), (270, 480, 2), (37, 53, 2)])
+def test_one_kernel_and_two_kernel_forms_of_the_system_give_the_same_bits(gpu, h, w, levels, monkeypatch):
+    """k_flow_system (the default: flow -> solver operands in one launch) against the pair of kernels it replaces
+    (k_warp_smooth_blend + k_assemble_skew, still the path of the other branches; PAPOF_FUSED_SYSTEM=0): same bits, on sizes
+    with ragged tiles at both borders; gray frames (3 feature channels) too."""
+    res = "240" if w <= 240 else "480"
+    a, b = cases.load_pair(res)
+    a, b = np.ascontiguousarray(a[:h, :w]), np.ascontiguousarray(b[:h, :w])
+    one = gpu.coarse2fine_flow(a, b, levels)[:3]
+    g1 = gpu.coarse2fine_flow(np.ascontiguousarray(a[..., :1]), np.ascontiguousarray(b[..., :1]), levels)[:3]
+    monkeypatch.setenv("PAPOF_FUSED_SYSTEM", "0")
+    two = gpu.coarse2fine_flow(a, b, levels)[:3]
+    g2 = gpu.coarse2fine_flow(np.ascontiguousarray(a[..., :1]), np.ascontiguousarray(b[..., :1]), levels)[:3]
+    for x, y in zip(one + g1, two + g2):
+        assert np.array_equal(x, y)
+
+
 def _tiny_scale_pair(res="240", scale=1e-21):
     """float frames whose every |Im1 - warpIm2| is ~1e-21: each feature channel's noise estimate is below 1E-20 from the
     first outer iteration on, so the reference's guard leaves every psi at 0 from the second one on"""
