@@ -334,8 +334,9 @@ int smooth_flow(papof_handle* h, const double* f1, const double* f2, double* war
     // ONE kernel from the flow to the linear system (k_flow_system) where it applies: default branches, exact-order layout
     const char* const fused_sw = std::getenv("PAPOF_FUSED_SYSTEM");  // A/B switch, and how the tests reach the pair of kernels
     const bool fused_env = !(fused_sw && fused_sw[0] == '0');
-    const bool fused_system = fused_env && fold_warp && n_inner == 1 && SP.skew && !B.gm && (fc == 5 || fc == 3) &&
-                              !(lg && lg->guard());
+    // (a one-block level keeps the pair of kernels while the guard collects proofs: their exhaustive check needs ONE block)
+    const bool fused_system = fused_env && fold_warp && n_inner == 1 && !B.gm && (fc == 5 || fc == 3) &&
+                              !(lg && lg->guard()) && !(lg && lg->on && lap_one_block_level(H, W));
     for (int count = 0; count < n_outer; count++) {
         clk.phase(fused_system ? kTimerFused : (int)PAPOF_T_PHASE1_GENERATE);
         if (fused_system)

@@ -967,12 +967,16 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
 // ------------------------------------------------------------------------------------------------
 constexpr int kFT = 16, kFH = 4, kFW = kFT + 2 * kFH;  // tile, halo, tile with halo
 // [163 registers: three workgroups per CU; forcing four or five waves per SIMD spills: 11.2 / 12.8 ms per 1080p pair against 10.35]
-template <int PLANES>
+// SKEW: the operands go to the exact-order solver's paired, skewed planes (pa, pb, pc); otherwise to six row-major planes
+// (q[0..5] = phi, xy, a1, a2, b1, b2: the one-workgroup solver of the small levels, k_sor_tiny).
+struct SixPlanes {
+    double* q[6];
+};
+template <int PLANES, bool SKEW>
 __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ im1, const double* __restrict__ im2,
                                                      const double* __restrict__ u, const double* __restrict__ v,
                                                      const double* __restrict__ im1s, int H, int W, double alpha,
-                                                     double omega, SkewIdx sk, double2s* __restrict__ pa,
-                                                     double2s* __restrict__ pb, double2s* __restrict__ pc, Taps g, Taps d,
+                                                     double omega, SkewIdx sk, SixPlanes out, Taps g, Taps d,
                                                      unsigned long long* stamp, unsigned* __restrict__ wit, double wit_thr,
                                                      unsigned mark) {
     __shared__ double raw[kFW][kFW + 1];            // warped frame 2, pixels (ib - 4 .. ib + 19) x (j0 - 4 .. j0 + 19)
@@ -1190,13 +1194,28 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
         if (i > 0) coeff += pu;
         if (i < H - 1) coeff += pc_;
         coeff *= alpha;
-        stage[0][orow][ocol] = pc_;
-        stage[1][orow][ocol] = sxy;
-        stage[2][orow][ocol] = omega / (sx2 + alpha * 0.05 + coeff);
-        stage[3][orow][ocol] = omega / (sy2 + alpha * 0.05 + coeff);
-        stage[4][orow][ocol] = -stx - alpha * lu;
-        stage[5][orow][ocol] = -sty - alpha * lv;
+        const double a1 = omega / (sx2 + alpha * 0.05 + coeff), a2 = omega / (sy2 + alpha * 0.05 + coeff);
+        const double b1 = -stx - alpha * lu, b2 = -sty - alpha * lv;
+        if (SKEW) {
+            stage[0][orow][ocol] = pc_;
+            stage[1][orow][ocol] = sxy;
+            stage[2][orow][ocol] = a1;
+            stage[3][orow][ocol] = a2;
+            stage[4][orow][ocol] = b1;
+            stage[5][orow][ocol] = b2;
+        } else {
+            out.q[0][o] = pc_;
+            out.q[1][o] = sxy;
+            out.q[2][o] = a1;
+            out.q[3][o] = a2;
+            out.q[4][o] = b1;
+            out.q[5][o] = b2;
+        }
     }
+    if (!SKEW) return;
+    double2s* const pa = reinterpret_cast<double2s*>(out.q[0]);
+    double2s* const pb = reinterpret_cast<double2s*>(out.q[2]);
+    double2s* const pc = reinterpret_cast<double2s*>(out.q[4]);
     __syncthreads();
     // ---- written in skew order, as k_assemble_skew does: a group of 16 threads stores 16 neighbouring rows of one position
     const int grp = tid / kFT, jj = tid - grp * kFT;
@@ -1783,12 +1802,14 @@ int assemble_system(papof_handle* h, const double* blend, const double* imdt, co
 // feature channels); returns PAPOF_EINVAL where it does not apply
 int flow_system(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, const double* im1s,
                 int H, int W, int planes, double alpha, double omega, const SorPlanes& out, unsigned* wit) {
-    if (!out.skew || (planes != 5 && planes != 3)) return PAPOF_EINVAL;
+    if (planes != 5 && planes != 3) return PAPOF_EINVAL;
     const dim3 grid((W + kFT - 1) / kFT, (H + kFT - 1) / kFT);
-    const auto kern = planes == 5 ? k_flow_system<5> : k_flow_system<3>;
-    hipLaunchKernelGGL(kern, grid, dim3(256), 0, h->stream, im1, im2, u, v, im1s, H, W, alpha, omega, skew_idx(out),
-                       (double2s*)out.phi, (double2s*)out.a1, (double2s*)out.b1, smooth5_taps(), deriv5_taps(), take_stamp(h),
-                       wit, 2e-20 * (double)H * (double)W, h->lap_epoch);
+    const SixPlanes six{{out.phi, out.xy, out.a1, out.a2, out.b1, out.b2}};
+    const auto kern = out.skew ? (planes == 5 ? k_flow_system<5, true> : k_flow_system<3, true>)
+                               : (planes == 5 ? k_flow_system<5, false> : k_flow_system<3, false>);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, h->stream, im1, im2, u, v, im1s, H, W, alpha, omega,
+                       out.skew ? skew_idx(out) : SkewIdx{0, 0, 0, 0, 0, 0, 0, 0, 0}, six, smooth5_taps(), deriv5_taps(),
+                       take_stamp(h), wit, 2e-20 * (double)H * (double)W, h->lap_epoch);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
