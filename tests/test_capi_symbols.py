@@ -82,3 +82,15 @@ def test_pyflow_argument_checks_without_gpu(lib):
     if lib.papof_device_count() == 0:
         with pytest.raises(RuntimeError):
             pyflow.coarse2fine_flow(a, a, 2)
+
+
+def test_collection_in_flight_policy_and_setter_arguments(lib):
+    """flow_collection()'s default number of sequences in flight is a function of the frame size (tools/collection_probe.py on
+    MI355X); the C-ABI switches it relies on refuse a null handle instead of crashing."""
+    from papteam_opticalflow_amd import capi, collection_in_flight
+    sizes = [(135, 240), (270, 480), (540, 960), (1080, 1920), (2160, 3840)]
+    got = [collection_in_flight(h, w) for h, w in sizes]
+    assert got == [16, 16, 8, 4, 4] and got == sorted(got, reverse=True)
+    assert lib.papof_set_stream_overlap(None, 0) == capi.EINVAL if hasattr(capi, "EINVAL") else lib.papof_set_stream_overlap(None, 0) != 0
+    out = (capi.c_int * 4)()
+    assert lib.papof_lap_guard_stats(None, out) != 0
