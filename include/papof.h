@@ -352,7 +352,10 @@ int papof_last_sor_solves(papof_handle* h, int cap, int* n, int* info, double* s
  * out[2] = 1 when the next call will start in the exact pass, out[3] = 0 when PAPOF_LAP_GUARD=0 switched the guard off (an
  * A/B switch for its cost: results then differ from the reference's on tripping inputs).  hipGraph replay, the bicubic
  * branch and the papof_stage_smoothflow* entry points always take the exact pass; the Gaussian-mixture branch has no such
- * guard (:381-397); the multi-rank paths (papof_tiles_*) run without it. */
+ * guard (:381-397).  One pair over several ranks (papof_tiles_*): the exact-order band split has no exact pass, so it PROVES
+ * per call that the guard cannot have tripped (every rank checks every pixel of its rows behind every update; the flags of
+ * all ranks are gathered) or returns PAPOF_EINVAL on every rank with a message that names the one-GPU call; the red-black
+ * tiles -- not the reference's sweep order anyway -- run without the guard. */
 int papof_lap_guard_stats(papof_handle* h, int out[4]);
 
 /* Test aid: the strip schedule (api.hip: smooth_flow_strips) a level of height x width with `n_sor` sweeps and

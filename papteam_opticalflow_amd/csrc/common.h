@@ -376,6 +376,8 @@ int assemble_system(papof_handle* h, const double* blend, const double* imdt, co
 int flow_system(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, const double* im1s,
                 int H, int W, int planes, double alpha, double omega, const SorPlanes& out, unsigned* wit = nullptr);
 int lap_scratch_doubles();
+int lap_rows_check(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H, int W,
+                   int C, int r0, int r1, unsigned* wit, unsigned* val, unsigned mark);  // rows r0 .. r1-1, every pixel
 bool lap_one_block_level(int H, int W);  // k_warp_smooth_blend runs one block per channel: exhaustive check of the guard
 int lap_small_check(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H, int W,
                     int C, unsigned* wit);  // the same check for the flow behind the last update of such a level

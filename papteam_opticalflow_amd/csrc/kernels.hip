@@ -2053,6 +2053,39 @@ static __global__ __launch_bounds__(256) void k_lap_small(const double* __restri
     const int any_hit = __syncthreads_or(hit ? 1 : 0), any_valid = __syncthreads_or(valid ? 1 : 0);
     if (threadIdx.x == 0 && (any_hit || !any_valid)) wit[blockIdx.x] = any_hit ? mark : (mark ^ kLapNone);
 }
+// The same two flags over a RANGE OF ROWS (every pixel of rows r0 .. r1-1), for a rank of the exact-order band split
+// (tiles.hip: bands_flow): wit[k] = mark when a sample witnesses, val[k] = mark when the rows hold a valid sample at all.
+// Proofs combine over the ranks: a witness anywhere, or no valid sample anywhere.
+static __global__ __launch_bounds__(256) void k_lap_rows(const double* __restrict__ im1, const double* __restrict__ im2,
+                                                      const double* __restrict__ u, const double* __restrict__ v, int H,
+                                                      int W, int r0, int r1, unsigned* __restrict__ wit,
+                                                      unsigned* __restrict__ val, double wit_thr, unsigned mark) {
+    const size_t np = (size_t)H * W;
+    const double *p1 = im1 + blockIdx.y * np, *p2 = im2 + blockIdx.y * np;
+    bool hit = false, valid = false;
+    const int n = (r1 - r0) * W;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
+        const int i = r0 + c / W, j = c - (c / W) * W;
+        const size_t o = (size_t)i * W + j;
+        const double d = fabs(p1[o] - warp_value(p1, p2, u[o], v[o], i, j, H, W));
+        valid = valid || (d > 0 && d < 1000000);
+        hit = hit || (d >= wit_thr && d < 1000000);
+    }
+    const int any_hit = __syncthreads_or(hit ? 1 : 0), any_valid = __syncthreads_or(valid ? 1 : 0);
+    if (threadIdx.x == 0) {
+        if (any_hit) wit[blockIdx.y] = mark;
+        if (any_valid) val[blockIdx.y] = mark;
+    }
+}
+int lap_rows_check(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H, int W,
+                   int C, int r0, int r1, unsigned* wit, unsigned* val, unsigned mark) {
+    if (r1 <= r0) return PAPOF_OK;
+    const int blocks = std::min(256, ((r1 - r0) * W + 255) / 256);
+    hipLaunchKernelGGL(k_lap_rows, dim3(blocks, C), dim3(256), 0, h->stream, im1, im2, u, v, H, W, r0, r1, wit, val,
+                       2e-20 * (double)H * (double)W, mark);
+    LAUNCH_CHECK();
+    return PAPOF_OK;
+}
 bool lap_one_block_level(int H, int W) { return H <= kWsRows && W <= BX; }
 int lap_small_check(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H, int W,
                     int C, unsigned* wit) {

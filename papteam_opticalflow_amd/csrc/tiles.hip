@@ -732,7 +732,8 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     std::vector<PyrPlan> plan;
     PAPOF_TRY(pyramid_plan(H, W, P.ratio, levels, L, plan));
     h->seq.valid = false;
-    PAPOF_TRY(ensure_arena(h, arena_bytes_for(H, W, C, levels, n_sor_max, P.ratio) + (size_t)H * W * C * sizeof(double)));
+    PAPOF_TRY(ensure_arena(h, arena_bytes_for(H, W, C, levels, n_sor_max, P.ratio) + (size_t)H * W * C * sizeof(double) +
+                              (size_t)(t.tp->nranks + 2) * kLapMaxSlots * 8 * sizeof(unsigned)));  // + the guard's flags of all ranks
     Arena& A = h->arena;
     A.off = 0;
     A.overflow = false;
@@ -756,6 +757,21 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     }
     double* tmp_a = A.f64(np0 * C);
     double* tmp_b = A.f64(np0 * C);
+    // ---- the Laplacian-noise guard (api.hip: LapGuard; src/OpticalFlow.cpp:399-400).  This path runs the OPTIMISTIC pass only,
+    // so it must PROVE that the guard cannot have tripped, or refuse: behind every update each rank checks every pixel of the
+    // rows it owns -- a witness (|Im1 - warpIm2| >= 2e-20 x pixels), and whether there is a valid sample at all -- and at the end
+    // of the call the flags of all ranks are gathered: an estimate is proven when SOME rank has a witness or NO rank has a valid
+    // sample (the constant 0.001).  A consulted estimate without a proof ends the call with PAPOF_EINVAL on every rank: such a
+    // pair (values scaled to ~1e-21) belongs on the one-GPU call, which has the exact pass.
+    long lap_slots = 0;
+    for (int k = 0; k < levels; k++) lap_slots += P.n_outer + (long)k * P.n_outer_per_level;
+    const bool lap_on = h->lap_guard && fc <= 8 && lap_slots <= kLapMaxSlots / 2;
+    const size_t lap_words = (size_t)std::max<long>(lap_slots, 1) * 16;       // per rank: 8 witness + 8 valid words per slot
+    unsigned* lap_mine = reinterpret_cast<unsigned*>(A.f64(lap_words / 2));   // [slot][0..7] witness, [slot][8..15] valid
+    unsigned* lap_all = reinterpret_cast<unsigned*>(A.f64(lap_words / 2 * (size_t)n));  // every rank's, by rank
+    constexpr unsigned kLapSet = 1u;  // (the flags are cleared by every call: a set flag needs no pass number here)
+    if (lap_on) PAPOF_HIP(hipMemsetAsync(lap_mine, 0, lap_words * sizeof(unsigned), h->stream));
+    long lap_slot = 0;
     std::vector<double*> F1(levels), F2(levels);
     for (int k = 0; k < levels; k++) {
         const size_t nn = (size_t)L[k].w * L[k].h * fc;
@@ -994,6 +1010,12 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
             std::swap(v, v2);
             double* uv[2] = {u, v};
             PAPOF_TRY(exchange_planes(t, uv, 2, lw, own, need_u));
+            if (lap_on) {  // the noise estimate behind this update (:530), on the rows whose final flow this rank holds
+                const Rect Rf = own(me);
+                PAPOF_TRY(lap_rows_check(h, f1, f2, u, v, lh, lw, fc, Rf.y0, Rf.y1, lap_mine + lap_slot * 16,
+                                         lap_mine + lap_slot * 16 + 8, kLapSet));
+                lap_slot++;
+            }
             if (mine && count + 1 < n_outer) PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc, &Rw));  // :516
         }
         pw = lw;
@@ -1030,10 +1052,40 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
             PAPOF_HIP(hipMemcpyAsync(d_warp, warp_hwc, np0 * C * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         }
     }
+    std::vector<unsigned> lap_host;
+    if (lap_on) {  // every rank's flags to every rank: all of them reach the same verdict
+        const size_t msg = lap_words / 2;  // doubles
+        PAPOF_HIP(hipMemcpyAsync(lap_all + (size_t)me * lap_words, lap_mine, lap_words * sizeof(unsigned), hipMemcpyDeviceToDevice,
+                                 h->stream));
+        std::vector<Msg> sends, recvs;
+        for (int r = 0; r < n; r++)
+            if (r != me) {
+                sends.push_back(Msg{r, reinterpret_cast<double*>(lap_mine), msg});
+                recvs.push_back(Msg{r, reinterpret_cast<double*>(lap_all + (size_t)r * lap_words), msg});
+            }
+        if (n > 1) PAPOF_TRY(t.tp->exchange(h, sends, recvs));
+        lap_host.resize(lap_words * (size_t)n);
+        PAPOF_HIP(hipMemcpyAsync(lap_host.data(), lap_all, lap_host.size() * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    }
     total.phase(-1);
     PAPOF_HIP(hipStreamSynchronize(h->stream));
     if (overlap) PAPOF_HIP(hipStreamSynchronize(h->prep_stream));
     PAPOF_TRY(sor_check(h));  // PAPOF_ETIMEOUT when a bounded wait of this rank's tasks expired (a peer that never published)
+    if (lap_on) {
+        for (long s = 0; s + 1 < lap_slot; s++)  // the estimate behind the call's last update is never consulted
+            for (int c = 0; c < fc; c++) {
+                bool witness = false, valid = false;
+                for (int r = 0; r < n; r++) {
+                    witness = witness || lap_host[(size_t)r * lap_words + s * 16 + c] == kLapSet;
+                    valid = valid || lap_host[(size_t)r * lap_words + s * 16 + 8 + c] == kLapSet;
+                }
+                if (!witness && valid) {
+                    set_last_error_text("the reference's Laplacian-noise guard (LapPara < 1E-20, src/OpticalFlow.cpp:399-400) may "
+                                        "trip on this pair; the band split has no exact pass: run it on one GPU (papof_flow*)");
+                    return PAPOF_EINVAL;
+                }
+            }
+    }
     if (total.err != PAPOF_OK || sorclk.err != PAPOF_OK) return PAPOF_EDEVICE;
     sorclk.collect(tm);
     total.collect(tm);

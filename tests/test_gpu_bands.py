@@ -146,6 +146,25 @@ def test_band_split_rejects_what_it_does_not_cover(gpu):
             _run(2, a, b, 2, _params(**kw))
 
 
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_band_split_proves_the_laplacian_noise_guard_or_refuses(gpu, nranks):
+    """The band split runs without the noise estimate, so it must PROVE that the reference's `LapPara < 1E-20` guard
+    (src/OpticalFlow.cpp:399-400) cannot have tripped -- every rank checks every pixel of its rows behind every update, the
+    flags of all ranks are gathered -- or refuse the pair.  Ordinary frames: proven (the other tests of this file).  Duplicate
+    frames: no valid sample on any rank, proven, and the bits of the one-GPU call.  A pair scaled to 1e-21, on which the guard
+    does trip: every rank returns an error that names the one-GPU call."""
+    from papteam_opticalflow_amd import PapofError
+    a, b = cases.load_pair("240")
+    P = _params()
+    (vx, vy, wi, _), _ = _run(nranks, a, a, 3, P)
+    want = gpu.coarse2fine_flow(a, a, 3, P)
+    assert np.array_equal(vx, want[0]) and np.array_equal(vy, want[1]) and np.array_equal(wi, want[2])
+    assert not vx.any() and not vy.any()
+    with pytest.raises(PapofError) as e:
+        _run(nranks, np.ascontiguousarray(a * 1e-21), np.ascontiguousarray(b * 1e-21), 3, P)
+    assert "guard" in str(e.value) and "one GPU" in str(e.value)
+
+
 def test_a_peer_that_never_publishes_ends_in_a_timeout_not_a_hang(monkeypatch):
     """The bounded waits across the cut: rank 0 never launches its solver kernels (PAPOF_BANDS_SILENT_RANK), so the first
     band of rank 1 never sees progress of the band above it.  Its tasks must give up after their bounded spin, raise their
