@@ -988,6 +988,7 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
     stamp_now(stamp);
     const int ib = blockIdx.y * kFT, j0 = blockIdx.x * kFT, tid = threadIdx.x;
     const size_t np = (size_t)H * W;
+    const bool interior = ib >= kFH && ib + kFT + kFH <= H && j0 >= kFH && j0 + kFT + kFH <= W;  // block-uniform
     // ---- bilinear taps of the tile's pixels, once for all channels: (x0, y0), (dx, dy), or "outside" (frame 1's value)
     constexpr int kPer = (kFW * kFW + 255) / 256;  // 3
     int t_o[kPer], t_x0[kPer], t_y0[kPer];
@@ -1101,14 +1102,24 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
         if (k + 1 < PLANES) load_gathers(k + 1);
         __syncthreads();
         // -- P2: horizontal pass on every row of the tile, columns j0 - 2 .. j0 + 17
-        for (int c = tid; c < kFW * (kFT + 4); c += 256) {
-            const int r = c / (kFT + 4), cc = c - r * (kFT + 4);
-            const int i = ib - kFH + r, j = j0 - 2 + cc;
-            if (i < 0 || i >= H || j < 0 || j >= W) continue;
-            double acc = 0.0;
+        if (interior) {  // (block-uniform: every pixel of the tile + 4 is inside the image -- no clamps, no tests)
+            for (int c = tid; c < kFW * (kFT + 4); c += 256) {
+                const int r = c / (kFT + 4), cc = c - r * (kFT + 4);
+                double acc = 0.0;
 #pragma unroll
-            for (int l = -2; l <= 2; l++) acc += raw[r][clampi(j + l, W) - (j0 - kFH)] * g.t[l + 2];
-            hs[r][cc] = acc;
+                for (int l = -2; l <= 2; l++) acc += raw[r][cc + 2 + l] * g.t[l + 2];
+                hs[r][cc] = acc;
+            }
+        } else {
+            for (int c = tid; c < kFW * (kFT + 4); c += 256) {
+                const int r = c / (kFT + 4), cc = c - r * (kFT + 4);
+                const int i = ib - kFH + r, j = j0 - 2 + cc;
+                if (i < 0 || i >= H || j < 0 || j >= W) continue;
+                double acc = 0.0;
+#pragma unroll
+                for (int l = -2; l <= 2; l++) acc += raw[r][clampi(j + l, W) - (j0 - kFH)] * g.t[l + 2];
+                hs[r][cc] = acc;
+            }
         }
         __syncthreads();
         // -- P3: vertical pass, blend and imdt on (ib - 2 .. ib + 17) x (j0 - 2 .. j0 + 17)
@@ -1118,8 +1129,13 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
             const int i = ib - 2 + r, j = j0 - 2 + cc;
             if (c >= (kFT + 4) * (kFT + 4) || i < 0 || i >= H || j < 0 || j >= W) continue;
             double s2 = 0.0;
+            if (interior) {
 #pragma unroll
-            for (int l = -2; l <= 2; l++) s2 += hs[clampi(i + l, H) - (ib - kFH)][cc] * g.t[l + 2];
+                for (int l = -2; l <= 2; l++) s2 += hs[r + 2 + l][cc] * g.t[l + 2];
+            } else {
+#pragma unroll
+                for (int l = -2; l <= 2; l++) s2 += hs[clampi(i + l, H) - (ib - kFH)][cc] * g.t[l + 2];
+            }
             const double s1 = s1v[q];
             double t = s1;
             t *= 0.4;
@@ -1132,10 +1148,17 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
         // -- P4: derivatives, psi and the channel's terms of the own cell (assemble_cell, FAST)
         if (own) {
             double gx = 0.0, gy = 0.0;
+            if (interior) {
 #pragma unroll
-            for (int l = -2; l <= 2; l++) gx += bl[orow + 2][clampi(oj + l, W) - (j0 - 2)] * d.t[l + 2];
+                for (int l = -2; l <= 2; l++) gx += bl[orow + 2][ocol + 2 + l] * d.t[l + 2];
 #pragma unroll
-            for (int l = -2; l <= 2; l++) gy += bl[clampi(oi + l, H) - (ib - 2)][ocol + 2] * d.t[l + 2];
+                for (int l = -2; l <= 2; l++) gy += bl[orow + 2 + l][ocol + 2] * d.t[l + 2];
+            } else {
+#pragma unroll
+                for (int l = -2; l <= 2; l++) gx += bl[orow + 2][clampi(oj + l, W) - (j0 - 2)] * d.t[l + 2];
+#pragma unroll
+                for (int l = -2; l <= 2; l++) gy += bl[clampi(oi + l, H) - (ib - 2)][ocol + 2] * d.t[l + 2];
+            }
             const double gt = it[orow][ocol];
             double t = gt;
             t *= t;
