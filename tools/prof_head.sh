@@ -14,6 +14,7 @@ db=$(find $out/${tag}_prof -name "*.db" | head -1)
 python3 tools/rocpd_export.py stats $db $out/${tag}_kernel_stats.csv
 python3 tools/kernel_avgs.py $db > $out/${tag}_kernel_avgs_by_grid.txt
 python3 tools/call_timeline.py $db 4 > $out/${tag}_timeline_one_call.txt || true
+python3 tools/timeline_gaps.py $db 4 > $out/${tag}_timeline_gaps.txt || true
 rm -rf $out/${tag}_prof
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $out/${tag}_pmc_$c -o run -- python3 bench.py --no-cpu-baseline --no-collection --steps 3 --warmup 1 > /dev/null 2> $out/${tag}_pmc.err
