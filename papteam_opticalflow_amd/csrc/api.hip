@@ -112,6 +112,7 @@ size_t arena_bytes_for(int H, int W, int C, int levels, int n_sor_max, double ra
     size_t bytes = planes * np * sizeof(double);
     bytes += 3 * (sor_cells + 2 * kLanes) * 16 + (sor_cells_d + 2 * kLanes) * 16 + 10 * np * sizeof(double);  // SOR operands
     bytes += per_level + np * fc * sizeof(double);  // + the preparation stream's own filter temporary
+    bytes += 8 * (std::min<size_t>(kTinyMaxCells, np) * sizeof(double) + 256);  // the row-major operands of k_sor_tiny's levels
     bytes += (size_t)64 * 4096;            // alignment slack
     return bytes;
 }
@@ -225,7 +226,9 @@ int alloc_solve_buffers(Arena& A, int H, int W, int fc, int mode, int n_sor_cap,
     B.imdt = A.f64(np * fc);
     B.phi = A.f64(np);
     PAPOF_TRY(sor_alloc_planes(A, H, W, mode, n_sor_cap, B.sp));
-    if (mode == PAPOF_SOR_EXACT) PAPOF_TRY(sor_alloc_tiny_planes(A, kTinyMaxCells, B.sp_tiny));
+    // (the largest level k_sor_tiny can get is the frame itself: a frame of a few pixels must not ask for 8192 cells)
+    if (mode == PAPOF_SOR_EXACT)
+        PAPOF_TRY(sor_alloc_tiny_planes(A, std::min<size_t>(kTinyMaxCells, (size_t)H * W), B.sp_tiny));
     return A.overflow ? PAPOF_ENOMEM : PAPOF_OK;
 }
 

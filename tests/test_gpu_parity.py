@@ -638,6 +638,21 @@ def test_one_kernel_and_two_kernel_forms_of_the_system_give_the_same_bits(gpu, h
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("h,w", [(1, 9), (3, 4), (5, 7), (16, 33), (17, 16), (2, 2)])
+def test_frames_of_a_few_pixels(gpu, oracle, h, w):
+    """Frames far smaller than any tile (the arena once asked for the one-workgroup solver's full 8192-cell planes whatever the
+    frame size: PAPOF_ENOMEM below ~25 x 25 pixels): one level, and as many levels as the size allows, against the oracle."""
+    a, b = cases.load_pair("240")
+    a, b = np.ascontiguousarray(a[40:40 + h, 60:60 + w]), np.ascontiguousarray(b[40:40 + h, 60:60 + w])
+    for levels in (1, 2):
+        if levels == 2 and (int(h * 0.75) < 1 or int(w * 0.75) < 1):
+            continue
+        got = gpu.coarse2fine_flow(a, b, levels)[:3]
+        want = oracle.coarse2fine_flow(a, b, levels)[:3]
+        for name, x, y in zip(("vx", "vy", "warpI2"), got, want):
+            _cmp("%dx%d L%d %s" % (h, w, levels, name), x, y, TOL_SOLVE)
+
+
 def _tiny_scale_pair(res="240", scale=1e-21):
     """float frames whose every |Im1 - warpIm2| is ~1e-21: each feature channel's noise estimate is below 1E-20 from the
     first outer iteration on, so the reference's guard leaves every psi at 0 from the second one on"""
