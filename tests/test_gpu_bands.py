@@ -182,3 +182,23 @@ def test_a_peer_that_never_publishes_ends_in_a_timeout_not_a_hang(monkeypatch):
     monkeypatch.delenv("PAPOF_BANDS_SILENT_RANK")
     (vx, vy, wi, _), _ = _run(2, a, b, 1, _params(n_outer=1, n_outer_per_level=0, n_sor=5, n_sor_per_level=0))  # and works afterwards
     assert np.isfinite(vx).all()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_band_split_random_shapes_ranks_and_schedules(gpu, seed):
+    """Random frame sizes (one to five solver bands), rank counts (more ranks than bands included), pyramid depths and schedules:
+    the split returns the bits of the one-GPU exact call."""
+    rng = np.random.default_rng(3000 + seed)
+    a0, b0 = cases.load_pair("480")
+    for case in range(4):
+        h, w = int(rng.integers(40, 271)), int(rng.integers(40, 301))
+        y0, x0 = int(rng.integers(0, 270 - h + 1)), int(rng.integers(0, 480 - w + 1))
+        a, b = np.ascontiguousarray(a0[y0:y0 + h, x0:x0 + w]), np.ascontiguousarray(b0[y0:y0 + h, x0:x0 + w])
+        levels, nranks = int(rng.integers(1, 5)), int(rng.integers(2, 7))
+        kw = dict(n_outer=int(rng.integers(1, 4)), n_outer_per_level=int(rng.integers(0, 2)), n_sor=int(rng.integers(2, 50)),
+                  n_sor_per_level=int(rng.integers(0, 3)))
+        print("seed %d case %d: %dx%d L%d ranks %d %s" % (seed, case, h, w, levels, nranks, kw), flush=True)
+        P = _params(**kw)
+        (vx, vy, wi, _), _ = _run(nranks, a, b, levels, P)
+        want = gpu.coarse2fine_flow(a, b, levels, P)
+        assert np.array_equal(vx, want[0]) and np.array_equal(vy, want[1]) and np.array_equal(wi, want[2]), (seed, case)
