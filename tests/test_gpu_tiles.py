@@ -181,3 +181,32 @@ def test_bench_tiles_reporting_path_single_rank():
     ex = t["exact_order"]  # the same pair in the reference's sweep order, split over the ranks (bands_flow)
     assert "error" not in ex, ex
     assert ex["bit_identical_to_one_gpu_exact"] is True and ex["value"] > 0 and ex["n_ranks_seen"] == 1
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_tiles_random_grids_halos_and_shapes(gpu, seed):
+    """Random frame sizes, tile grids, ghost-zone depths, pyramid depths and schedules: whatever the tiled path accepts must be
+    bit-identical to the one-GPU red-black call (a grid it refuses is refused with PAPOF_EINVAL, not computed wrongly)."""
+    from papteam_opticalflow_amd import PapofError
+    rng = np.random.default_rng(4000 + seed)
+    a0, b0 = cases.load_pair("480")
+    done = 0
+    for case in range(6):
+        h, w = int(rng.integers(48, 271)), int(rng.integers(64, 481))
+        y0, x0 = int(rng.integers(0, 270 - h + 1)), int(rng.integers(0, 480 - w + 1))
+        a, b = np.ascontiguousarray(a0[y0:y0 + h, x0:x0 + w]), np.ascontiguousarray(b0[y0:y0 + h, x0:x0 + w])
+        rows, cols, halo = int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.integers(1, 11))
+        levels = int(rng.integers(1, 4))
+        kw = dict(n_outer=int(rng.integers(1, 3)), n_outer_per_level=int(rng.integers(0, 2)), n_sor=int(rng.integers(1, 25)),
+                  n_sor_per_level=int(rng.integers(0, 3)))
+        print("seed %d case %d: %dx%d L%d grid %dx%d halo %d %s" % (seed, case, h, w, levels, rows, cols, halo, kw), flush=True)
+        P = _params(**kw)
+        try:
+            (vx, vy, wi, _), _ = _run_tiles(rows * cols, rows, cols, halo, a, b, levels, P)
+        except PapofError as e:
+            assert e.code == -1, e  # PAPOF_EINVAL: a grid / halo the path does not take
+            continue
+        want = gpu.coarse2fine_flow(a, b, levels, P)
+        assert np.array_equal(vx, want[0]) and np.array_equal(vy, want[1]) and np.array_equal(wi, want[2]), (seed, case)
+        done += 1
+    assert done >= 2
