@@ -374,7 +374,8 @@ int assemble_system(papof_handle* h, const double* blend, const double* imdt, co
                     double* opt_imdx2, double* opt_imdy2, const SorPlanes* prev, const Rect* rc = nullptr,
                     const double* gm = nullptr, const double* lap = nullptr);
 int flow_system(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, const double* im1s,
-                int H, int W, int planes, double alpha, double omega, const SorPlanes& out, unsigned* wit = nullptr);
+                int H, int W, int planes, double alpha, double omega, const SorPlanes& out, unsigned* wit = nullptr,
+                int row0 = 0, int row1 = -1);  // rows row0 .. row1-1 (a rank's range of rows: tiles.hip)
 int lap_scratch_doubles();
 int lap_rows_check(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H, int W,
                    int C, int r0, int r1, unsigned* wit, unsigned* val, unsigned mark);  // rows r0 .. r1-1, every pixel

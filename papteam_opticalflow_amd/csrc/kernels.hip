@@ -978,7 +978,9 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
                                                      const double* __restrict__ im1s, int H, int W, double alpha,
                                                      double omega, SkewIdx sk, SixPlanes out, Taps g, Taps d,
                                                      unsigned long long* stamp, unsigned* __restrict__ wit, double wit_thr,
-                                                     unsigned mark) {
+                                                     unsigned mark, int row0, int row1) {
+    // rows row0 .. row1-1 are assembled (a rank's range of rows, tiles.hip: bands_flow; the whole plane otherwise): (u, v) are
+    // read on rows row0 - 4 .. row1 + 3 only, the smoothed frame 1 on row0 - 2 .. row1 + 1
     __shared__ double raw[kFW][kFW + 1];            // warped frame 2, pixels (ib - 4 .. ib + 19) x (j0 - 4 .. j0 + 19)
     __shared__ double hs[kFW][kFT + 4 + 1];         // h-smoothed, columns j0 - 2 .. j0 + 17
     __shared__ double bl[kFT + 4][kFT + 4 + 1];     // blend, pixels (ib - 2 .. ib + 17) x (j0 - 2 .. j0 + 17)
@@ -986,9 +988,10 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
     __shared__ double ph[kFT + 1][kFT + 1 + 1];     // phi, pixels (ib - 1 .. ib + 15) x (j0 - 1 .. j0 + 15)
     __shared__ double stage[6][kFT][kFT + 1];
     stamp_now(stamp);
-    const int ib = blockIdx.y * kFT, j0 = blockIdx.x * kFT, tid = threadIdx.x;
+    const int ib = row0 + blockIdx.y * kFT, j0 = blockIdx.x * kFT, tid = threadIdx.x;
     const size_t np = (size_t)H * W;
-    const bool interior = ib >= kFH && ib + kFT + kFH <= H && j0 >= kFH && j0 + kFT + kFH <= W;  // block-uniform
+    const int vy0 = max(0, row0 - kFH), vy1 = min(H, row1 + kFH);  // rows on which the operands are valid
+    const bool interior = ib >= vy0 + kFH && ib + kFT <= row1 && ib + kFT + kFH <= vy1 && j0 >= kFH && j0 + kFT + kFH <= W;  // block-uniform
     // ---- bilinear taps of the tile's pixels, once for all channels: (x0, y0), (dx, dy), or "outside" (frame 1's value)
     constexpr int kPer = (kFW * kFW + 255) / 256;  // 3
     int t_o[kPer], t_x0[kPer], t_y0[kPer];
@@ -998,7 +1001,7 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
     for (int q = 0; q < kPer; q++) {
         const int c = tid + q * 256, r = c / kFW, cc = c - r * kFW;
         const int i = ib - kFH + r, j = j0 - kFH + cc;
-        t_in[q] = c < kFW * kFW && i >= 0 && i < H && j >= 0 && j < W;
+        t_in[q] = c < kFW * kFW && i >= vy0 && i < vy1 && j >= 0 && j < W;
         t_o[q] = t_in[q] ? i * W + j : 0;
         double x = 0.0, y = 0.0;  // (a cell outside the image: any valid position, its value is not used)
         t_out[q] = false;
@@ -1020,7 +1023,7 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
     for (int c = tid; c < (kFT + 1) * (kFT + 1); c += 256) {
         const int r = c / (kFT + 1), cc = c - r * (kFT + 1);
         const int i = ib - 1 + r, j = j0 - 1 + cc;
-        if (i < 0 || i >= H || j < 0 || j >= W) continue;
+        if (i < 0 || i >= min(H, row1) || j < 0 || j >= W) continue;
         const size_t o = (size_t)i * W + j;
         const double uc = u[o], vc = v[o];
         double ur = 0.0, vr = 0.0, ud = 0.0, vd = 0.0;
@@ -1041,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
     }
     const int orow = tid / kFT, ocol = tid - orow * kFT;  // this thread's cell of the tile
     const int oi = ib + orow, oj = j0 + ocol;
-    const bool own = oi < H && oj < W;
+    const bool own = oi < row1 && oj < W;
     double sxy = 0.0, sx2 = 0.0, sy2 = 0.0, stx = 0.0, sty = 0.0;
     // witnesses of the Laplacian-noise guard (k_warp_smooth_blend): one block in sixteen on large grids, its first wave
     const bool sampler = wit != nullptr && tid < 64 &&
@@ -1248,7 +1251,7 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
         const int r = pp - jj;
         if (r < 0 || r >= kFT) continue;
         const int i = ib + r;
-        if (i >= H) continue;
+        if (i >= row1) continue;
         const size_t q = skew_cell(i, j, sk);
         pa[q] = double2s{stage[0][r][jj], stage[1][r][jj]};
         pb[q] = double2s{stage[2][r][jj], stage[3][r][jj]};
@@ -1824,15 +1827,18 @@ int assemble_system(papof_handle* h, const double* blend, const double* imdt, co
 // k_flow_system: the default branches of warp_smooth_blend() + assemble_system() in one launch (exact-order layout, 5 or 3
 // feature channels); returns PAPOF_EINVAL where it does not apply
 int flow_system(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, const double* im1s,
-                int H, int W, int planes, double alpha, double omega, const SorPlanes& out, unsigned* wit) {
+                int H, int W, int planes, double alpha, double omega, const SorPlanes& out, unsigned* wit, int row0, int row1) {
     if (planes != 5 && planes != 3) return PAPOF_EINVAL;
-    const dim3 grid((W + kFT - 1) / kFT, (H + kFT - 1) / kFT);
+    if (row1 < 0) row1 = H;
+    if (row0 < 0 || row1 > H) return PAPOF_EINVAL;
+    if (row1 <= row0) return PAPOF_OK;
+    const dim3 grid((W + kFT - 1) / kFT, (row1 - row0 + kFT - 1) / kFT);
     const SixPlanes six{{out.phi, out.xy, out.a1, out.a2, out.b1, out.b2}};
     const auto kern = out.skew ? (planes == 5 ? k_flow_system<5, true> : k_flow_system<3, true>)
                                : (planes == 5 ? k_flow_system<5, false> : k_flow_system<3, false>);
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, h->stream, im1, im2, u, v, im1s, H, W, alpha, omega,
                        out.skew ? skew_idx(out) : SkewIdx{0, 0, 0, 0, 0, 0, 0, 0, 0}, six, smooth5_taps(), deriv5_taps(),
-                       take_stamp(h), wit, 2e-20 * (double)H * (double)W, h->lap_epoch);
+                       take_stamp(h), wit, 2e-20 * (double)H * (double)W, h->lap_epoch, row0, row1);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }

@@ -772,6 +772,9 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     constexpr unsigned kLapSet = 1u;  // (the flags are cleared by every call: a set flag needs no pass number here)
     if (lap_on) PAPOF_HIP(hipMemsetAsync(lap_mine, 0, lap_words * sizeof(unsigned), h->stream));
     long lap_slot = 0;
+    // the default branches' one-kernel form of warp .. linear system (kernels.hip: k_flow_system), on each rank's rows
+    const char* const fused_sw = std::getenv("PAPOF_FUSED_SYSTEM");
+    const bool fused = !(fused_sw && fused_sw[0] == '0') && (fc == 5 || fc == 3);
     std::vector<double*> F1(levels), F2(levels);
     for (int k = 0; k < levels; k++) {
         const size_t nn = (size_t)L[k].w * L[k].h * fc;
@@ -933,7 +936,7 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
             PAPOF_TRY(resize(h, v, v2, ph, pw, 1, lh, lw, xr, yr, true, inv, &Rw));
             std::swap(u, u2);
             std::swap(v, v2);
-            PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc, &Rw));
+            if (!fused) PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc, &Rw));
         }
         // smoothed features of frame 1 on the rows the blend is needed on (getDxs, src/OpticalFlow.cpp:84-90)
         PAPOF_TRY(filter_h(h, f1, tmp, lh, lw, fc, g5, &Rw));
@@ -942,10 +945,14 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
         const int below = me + 1 < n && bs.has(me + 1) ? me + 1 : -1;
         for (int count = 0; count < n_outer; count++) {
             if (mine) {
-                PAPOF_TRY(smooth_hv_blend(h, warp, im1s, blend, imdt, lh, lw, fc, Rsm.y0, Rsm.y1));
-                PAPOF_TRY(compute_phi(h, u, v, nullptr, phi, lh, lw, &Rphi));
-                PAPOF_TRY(assemble_system(h, blend, imdt, phi, u, v, lh, lw, fc, P.alpha, P.omega, sp, nullptr, nullptr,
-                                          nullptr, &Rsys));
+                if (fused) {  // kernels.hip: k_flow_system on this rank's rows -- the warped frame is never materialised
+                    PAPOF_TRY(flow_system(h, f1, f2, u, v, im1s, lh, lw, fc, P.alpha, P.omega, sp, nullptr, Rsys.y0, Rsys.y1));
+                } else {
+                    PAPOF_TRY(smooth_hv_blend(h, warp, im1s, blend, imdt, lh, lw, fc, Rsm.y0, Rsm.y1));
+                    PAPOF_TRY(compute_phi(h, u, v, nullptr, phi, lh, lw, &Rphi));
+                    PAPOF_TRY(assemble_system(h, blend, imdt, phi, u, v, lh, lw, fc, P.alpha, P.omega, sp, nullptr, nullptr,
+                                              nullptr, &Rsys));
+                }
                 unsigned* const prog = h->sync_words + 32 + LP[k].off + (size_t)count * LP[k].per;
                 SorSplit cut{nullptr, nullptr, B0 > 0, below >= 0};
                 if (below >= 0 && direct) {
@@ -1016,7 +1023,7 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
                                          lap_mine + lap_slot * 16 + 8, kLapSet));
                 lap_slot++;
             }
-            if (mine && count + 1 < n_outer) PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc, &Rw));  // :516
+            if (mine && !fused && count + 1 < n_outer) PAPOF_TRY(warp_bilinear(h, f1, f2, u, v, warp, lh, lw, fc, &Rw));  // :516
         }
         pw = lw;
         ph = lh;
