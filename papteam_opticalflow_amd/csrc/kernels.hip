@@ -988,7 +988,13 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
     __shared__ double ph[kFT + 1][kFT + 1 + 1];     // phi, pixels (ib - 1 .. ib + 15) x (j0 - 1 .. j0 + 15)
     __shared__ double stage[6][kFT][kFT + 1];
     stamp_now(stamp);
-    const int ib = row0 + blockIdx.y * kFT, j0 = blockIdx.x * kFT, tid = threadIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (observed; speed only): give each XCD a contiguous run of tiles, so
+    // that the halo pixels neighbouring tiles both gather are found in that XCD's L2 (as k_sor_blocked does)
+    const int ntx = (W + kFT - 1) / kFT, ntiles = ntx * ((row1 - row0 + kFT - 1) / kFT), per = (ntiles + 7) >> 3;
+    const int vt = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || vt >= ntiles) return;  // whole workgroup, before any barrier
+    const int tby = vt / ntx, tbx = vt - tby * ntx;
+    const int ib = row0 + tby * kFT, j0 = tbx * kFT, tid = threadIdx.x;
     const size_t np = (size_t)H * W;
     const int vy0 = max(0, row0 - kFH), vy1 = min(H, row1 + kFH);  // rows on which the operands are valid
     const bool interior = ib >= vy0 + kFH && ib + kFT <= row1 && ib + kFT + kFH <= vy1 && j0 >= kFH && j0 + kFT + kFH <= W;  // block-uniform
@@ -1048,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
     double sxy = 0.0, sx2 = 0.0, sy2 = 0.0, stx = 0.0, sty = 0.0;
     // witnesses of the Laplacian-noise guard (k_warp_smooth_blend): one block in sixteen on large grids, its first wave
     const bool sampler = wit != nullptr && tid < 64 &&
-                         (gridDim.x * gridDim.y <= 256u || ((blockIdx.x + 5u * blockIdx.y) & 15u) == 0u);
+                         (ntiles <= 256 || ((tbx + 5 * tby) & 15) == 0);
     // The global operands of a channel are PREFETCHED while the previous channel is worked on (a workgroup barrier does not
     // wait for loads in flight): the gathers (or frame 1's value for a pixel that leaves the image) right behind P1, the smoothed
     // frame 1 of the blend's pixels right behind P3 -- the phases between are LDS only.
@@ -1832,7 +1838,8 @@ int flow_system(papof_handle* h, const double* im1, const double* im2, const dou
     if (row1 < 0) row1 = H;
     if (row0 < 0 || row1 > H) return PAPOF_EINVAL;
     if (row1 <= row0) return PAPOF_OK;
-    const dim3 grid((W + kFT - 1) / kFT, (row1 - row0 + kFT - 1) / kFT);
+    const int ntiles = ((W + kFT - 1) / kFT) * ((row1 - row0 + kFT - 1) / kFT);
+    const dim3 grid(8 * ((ntiles + 7) / 8));  // (the kernel maps block -> tile: a contiguous run of tiles per XCD)
     const SixPlanes six{{out.phi, out.xy, out.a1, out.a2, out.b1, out.b2}};
     const auto kern = out.skew ? (planes == 5 ? k_flow_system<5, true> : k_flow_system<3, true>)
                                : (planes == 5 ? k_flow_system<5, false> : k_flow_system<3, false>);
