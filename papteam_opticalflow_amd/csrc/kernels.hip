@@ -33,6 +33,19 @@ __device__ __forceinline__ int clampi(int x, int n) {  // EnforceRange, src/Imag
     return x > n - 1 ? n - 1 : x;
 }
 
+// Tiled kernels launched on a 1-D grid of xcd_grid(tiles) blocks (x; channels, if any, in z): workgroups are dealt round-robin
+// over the 8 XCDs (observed; speed only), so block b works on tile (b % 8) * per + b / 8 -- a contiguous run of tiles (row-major)
+// per XCD: the halo rows and columns neighbouring tiles both read are found in that XCD's L2.  false: no tile for this block.
+__device__ __forceinline__ bool xcd_tile(int ntx, int nty, int& tx, int& ty) {
+    const int ntiles = ntx * nty, per = (ntiles + 7) >> 3;
+    const int vt = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || vt >= ntiles) return false;
+    ty = vt / ntx;
+    tx = vt - ty * ntx;
+    return true;
+}
+static inline unsigned xcd_grid(int ntx, int nty) { return 8u * (unsigned)(((size_t)ntx * nty + 7) / 8); }
+
 // ------------------------------------------------------------------------------------------------
 // layout conversion (entry / exit of the call): HWC interleaved <-> planar
 // ------------------------------------------------------------------------------------------------
@@ -136,7 +149,9 @@ __global__ __launch_bounds__(256) void k_filter_hv_staged(const double* __restri
                                                           int W, Taps fh, Taps fv) {
     __shared__ double raw[kHvsRows + 2 * F][BX + 2 * F];
     __shared__ double hs[kHvsRows + 2 * F][BX];
-    const int j0 = blockIdx.x * BX, i0 = blockIdx.y * kHvsRows;
+    int tx, ty;
+    if (!xcd_tile((W + BX - 1) / BX, (H + kHvsRows - 1) / kHvsRows, tx, ty)) return;  // whole workgroup, before any barrier
+    const int j0 = tx * BX, i0 = ty * kHvsRows;
     const size_t np = (size_t)H * W;
     const double* plane = src + blockIdx.z * np;
     constexpr int kCells = (kHvsRows + 2 * F) * (BX + 2 * F);
@@ -261,7 +276,9 @@ __global__ __launch_bounds__(256) void k_im2feature_tiled(const double* __restri
     // frames has no valid sample for estLaplacianNoise (every |Im1 - warpIm2| is exactly 0), so its LapPara is 0.001 whatever
     // the flow (api.hip: LapGuard).  One ballot per wave, at most one store per wave and channel.
     __shared__ double g[kFeatRows + 4][BX + 4];
-    const int j0 = blockIdx.x * BX, i0 = blockIdx.y * kFeatRows;
+    int tx, ty;
+    if (!xcd_tile((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows, tx, ty)) return;  // whole workgroup, before any barrier
+    const int j0 = tx * BX, i0 = ty * kFeatRows;
     const size_t np = (size_t)H * W;
     for (int c = threadIdx.y * BX + threadIdx.x; c < (kFeatRows + 4) * (BX + 4); c += BX * BY) {
         const int r = c / (BX + 4), cc = c - r * (BX + 4);
@@ -1688,7 +1705,7 @@ int filter_hv(papof_handle* h, const double* src, double* dst, double* tmp, int 
     const dim3 grid((W + BX - 1) / BX, (H + kHvRows - 1) / kHvRows, planes), block(BX, BY);
     const int f = fh.fsize == fv.fsize ? fh.fsize : -1;
     if (PAPOF_V_HVSTAGED && f >= 1 && f <= 3) {
-        const dim3 sgrid((W + BX - 1) / BX, (H + kHvsRows - 1) / kHvsRows, planes);
+        const dim3 sgrid(xcd_grid((W + BX - 1) / BX, (H + kHvsRows - 1) / kHvsRows), 1, planes);
         if (f == 1)
             hipLaunchKernelGGL(k_filter_hv_staged<1>, sgrid, block, 0, h->stream, src, dst, H, W, fh, fv);
         else if (f == 2)
@@ -1722,10 +1739,10 @@ int resize(papof_handle* h, const double* src, double* dst, int sh, int sw, int 
 
 int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C, unsigned* nz) {
     if (C == 3) {
-        hipLaunchKernelGGL(k_im2feature_tiled<3>, dim3((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows), dim3(BX, BY), 0,
+        hipLaunchKernelGGL(k_im2feature_tiled<3>, dim3(xcd_grid((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows)), dim3(BX, BY), 0,
                            h->stream, im, feat, H, W, deriv5_taps(), nz, h->lap_epoch);
     } else if (C == 1) {
-        hipLaunchKernelGGL(k_im2feature_tiled<1>, dim3((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows), dim3(BX, BY), 0,
+        hipLaunchKernelGGL(k_im2feature_tiled<1>, dim3(xcd_grid((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows)), dim3(BX, BY), 0,
                            h->stream, im, feat, H, W, deriv5_taps(), nz, h->lap_epoch);
     } else {  // src/OpticalFlow.cpp:956-957: any other channel count is passed through
         PAPOF_HIP(hipMemcpyAsync(feat, im, sizeof(double) * (size_t)H * W * C, hipMemcpyDeviceToDevice, h->stream));
