@@ -221,7 +221,9 @@ __device__ __forceinline__ double bilinear_apply(const double* __restrict__ p, c
 __global__ void k_resize(const double* __restrict__ src, double* __restrict__ dst, int sh, int sw, int dh, int dw,
                          double xr, double yr, int use_post, double post, Rect rc, unsigned long long* stamp) {
     stamp_now(stamp);
-    const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
+    int tbx, tby;  // a contiguous run of blocks per XCD (xcd_tile): the four taps of neighbouring rows meet in one L2
+    if (!xcd_tile((rc.x1 - rc.x0 + BX - 1) / BX, (rc.y1 - rc.y0 + BY - 1) / BY, tbx, tby)) return;
+    const int j = rc.x0 + tbx * BX + threadIdx.x, i = rc.y0 + tby * BY + threadIdx.y;
     if (j >= rc.x1 || i >= rc.y1) return;
     const double x = (double)(j + 1) / xr - 1;
     const double y = (double)(i + 1) / yr - 1;
@@ -326,7 +328,9 @@ __global__ __launch_bounds__(256) void k_im2feature_tiled(const double* __restri
 // gxy = the v pass over gx, whose three rows are recomputed here with the h pass's own operations (same bits).
 __global__ void k_central3_all(const double* __restrict__ src, double* __restrict__ gx, double* __restrict__ gy,
                                double* __restrict__ gxy, int H, int W, Taps c3) {
-    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
+    int tbx, tby;
+    if (!xcd_tile((W + BX - 1) / BX, (H + BY - 1) / BY, tbx, tby)) return;
+    const int j = tbx * BX + threadIdx.x, i = tby * BY + threadIdx.y;
     if (j >= W || i >= H) return;
     const size_t np = (size_t)H * W;
     const double* p = src + blockIdx.z * np;
@@ -1354,7 +1358,9 @@ __global__ void k_update_warp_phi(const double* __restrict__ sdu, const double* 
                                   int do_warp, unsigned long long* stamp, int row0, int row1, unsigned* __restrict__ wit,
                                   double wit_thr, unsigned mark) {
     stamp_now(stamp);
-    const int j = blockIdx.x * BX + threadIdx.x, i = row0 + blockIdx.y * BY + threadIdx.y;  // rows row0 .. row1-1
+    int tbx, tby;  // a contiguous run of blocks per XCD (xcd_tile): blocks above each other share the lines of the banded (du, dv)
+    if (!xcd_tile((W + BX - 1) / BX, (row1 - row0 + BY - 1) / BY, tbx, tby)) return;
+    const int j = tbx * BX + threadIdx.x, i = row0 + tby * BY + threadIdx.y;  // rows row0 .. row1-1
     if (j >= W || i >= row1) return;
     const size_t o = (size_t)i * W + j;
     const auto inc = [&](int ii, int jj, double& a, double& b) {
@@ -1378,7 +1384,7 @@ __global__ void k_update_warp_phi(const double* __restrict__ sdu, const double* 
     // iteration follows on the level): behind the LAST update of a level nobody evaluates the warp at the new flow, so here the
     // first `planes` threads of every block evaluate it at their own pixel, one channel each.
     if (wit != nullptr) {
-        const int bw = min(W - (int)(blockIdx.x * BX), BX), bh = min(row1 - (int)(row0 + blockIdx.y * BY), BY);  // the block's pixels
+        const int bw = min(W - tbx * BX, BX), bh = min(row1 - (row0 + tby * BY), BY);  // the block's pixels
         const int lin = threadIdx.y * bw + threadIdx.x;
         const size_t np = (size_t)H * W;
         if (np <= 65536) {  // a coarse level: few blocks, so every thread samples (channel = its number within the block mod planes)
@@ -1387,7 +1393,7 @@ __global__ void k_update_warp_phi(const double* __restrict__ sdu, const double* 
                 const double d = fabs(im1[k * np + o] - w);
                 if (d >= wit_thr && d < 1000000) wit[k] = mark;
             }
-        } else if (((blockIdx.x + 5u * blockIdx.y) & 15u) == 0u)  // a large grid: one block in sixteen samples
+        } else if (((tbx + 5 * tby) & 15) == 0)  // a large grid: one block in sixteen samples
         for (int k = lin; k < planes; k += bw * bh) {  // (one trip of one thread per channel, unless the block has fewer pixels)
             const double w = warp_value(im1 + k * np, im2 + k * np, fu, fv, i, j, H, W);
             const double d = fabs(im1[k * np + o] - w);
@@ -1454,7 +1460,9 @@ __global__ void k_bicubic(const double* __restrict__ im1, const double* __restri
     // planar_out / clamp: the in-loop use on the feature planes (src/OpticalFlow.cpp:517-521 with threshold(), :816
     // without); the final warp of the originals writes interleaved HWC and always clamps.
     stamp_now(stamp);
-    const int j = rc.x0 + blockIdx.x * BX + threadIdx.x, i = rc.y0 + blockIdx.y * BY + threadIdx.y;
+    int tbx, tby;  // a contiguous run of blocks per XCD (xcd_tile)
+    if (!xcd_tile((rc.x1 - rc.x0 + BX - 1) / BX, (rc.y1 - rc.y0 + BY - 1) / BY, tbx, tby)) return;
+    const int j = rc.x0 + tbx * BX + threadIdx.x, i = rc.y0 + tby * BY + threadIdx.y;
     if (j >= rc.x1 || i >= rc.y1) return;
     const size_t np = (size_t)H * W, o = (size_t)i * W + j;
     const size_t ostride = planar_out ? np : 1, obase = planar_out ? o : o * C;
@@ -1688,7 +1696,7 @@ int filter_v(papof_handle* h, const double* src, double* dst, int H, int W, int 
 }
 
 int central3_planes(papof_handle* h, const double* src, double* gx, double* gy, double* gxy, int H, int W, int planes) {
-    hipLaunchKernelGGL(k_central3_all, grid2d(W, H, planes), dim3(BX, BY), 0, h->stream, src, gx, gy, gxy, H, W,
+    hipLaunchKernelGGL(k_central3_all, dim3(xcd_grid((W + BX - 1) / BX, (H + BY - 1) / BY), 1, planes), dim3(BX, BY), 0, h->stream, src, gx, gy, gxy, H, W,
                        central3_taps());
     LAUNCH_CHECK();
     return PAPOF_OK;
@@ -1731,7 +1739,7 @@ int resize(papof_handle* h, const double* src, double* dst, int sh, int sw, int 
            double yr, bool use_post, double post, const Rect* rc) {
     const Rect r = region(rc, dw, dh);
     if (r.empty()) return PAPOF_OK;
-    hipLaunchKernelGGL(k_resize, grid2d(r, planes), dim3(BX, BY), 0, h->stream, src, dst, sh, sw, dh, dw, xr, yr,
+    hipLaunchKernelGGL(k_resize, dim3(xcd_grid((r.x1 - r.x0 + BX - 1) / BX, (r.y1 - r.y0 + BY - 1) / BY), 1, planes), dim3(BX, BY), 0, h->stream, src, dst, sh, sw, dh, dw, xr, yr,
                        use_post ? 1 : 0, post, r, take_stamp(h));
     LAUNCH_CHECK();
     return PAPOF_OK;
@@ -1894,7 +1902,7 @@ int update_warp_phi(papof_handle* h, const SorPlanes& sp, const double* u, const
     if (row1 < 0) row1 = H;
     if (row0 < 0 || row1 > H) return PAPOF_EINVAL;
     if (row1 <= row0) return PAPOF_OK;
-    const dim3 grid = grid2d(W, row1 - row0);
+    const dim3 grid(xcd_grid((W + BX - 1) / BX, (row1 - row0 + BY - 1) / BY));
     if (sp.skew)
         hipLaunchKernelGGL(k_update_warp_phi<true>, grid, dim3(BX, BY), 0, h->stream, sp.du, sp.dv, skew_idx(sp),
                            u, v, u_out, v_out, im1, im2, warp, phi_out, H, W, planes, do_warp ? 1 : 0, take_stamp(h),
@@ -1947,7 +1955,7 @@ int bicubic_warp(papof_handle* h, const double* im1, const double* im2, const do
                  const Rect* rc, bool planar_out, bool clamp) {
     const Rect r = region(rc, W, H);
     if (r.empty()) return PAPOF_OK;
-    hipLaunchKernelGGL(k_bicubic, grid2d(r), dim3(BX, BY), 0, h->stream, im1, im2, gx, gy, gxy, vx, vy, out_hwc, H, W,
+    hipLaunchKernelGGL(k_bicubic, dim3(xcd_grid((r.x1 - r.x0 + BX - 1) / BX, (r.y1 - r.y0 + BY - 1) / BY)), dim3(BX, BY), 0, h->stream, im1, im2, gx, gy, gxy, vx, vy, out_hwc, H, W,
                        C, r, take_stamp(h), planar_out ? 1 : 0, clamp ? 1 : 0);
     LAUNCH_CHECK();
     return PAPOF_OK;
