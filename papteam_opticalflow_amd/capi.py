@@ -685,19 +685,16 @@ class TileRank:
             self.t = c_void_p()
 
 
-class LocalTileGroup:
-    """All ranks of a tile group inside this process (LOCAL transport: device copies instead of RCCL), each driven by
-    its own host thread.  For parity tests of the tiled path on a one-GPU box."""
+class _TileGroup:
+    """All ranks of a tile group inside this process, each driven by its own host thread: the parity tests of the sharded
+    paths on a one-GPU box."""
 
     def __init__(self, nranks, rows=0, cols=0, halo=0, device=0):
         if not rows:
             rows, cols = tiles_grid(nranks)
-        self.n, self.rows, self.cols = nranks, rows, cols
+        self.n, self.rows, self.cols, self.halo = nranks, rows, cols, halo
         self.gpus = [Papof(device) for _ in range(nranks)]
-        hs = (c_void_p * nranks)(*[g.h for g in self.gpus])
-        ts = (c_void_p * nranks)()
-        _chk(self.gpus[0].L.papof_tiles_create_local(hs, nranks, rows, cols, halo, ts), "papof_tiles_create_local")
-        self.ranks = [TileRank(g, c_void_p(t)) for g, t in zip(self.gpus, ts)]
+        self.ranks = []
 
     def coarse2fine_flow(self, im1, im2, levels, params):
         """Host arrays in / out (HWC float64); every rank gets its own device copy of the frames, as one process per
@@ -743,7 +740,53 @@ class LocalTileGroup:
         return vx, vy, wi, times[0]
 
     def close(self):
-        for r in self.ranks:
-            r.close()
+        import threading
+        # (a communicator's destruction may wait for its peers', as ncclCommDestroy does: one thread per rank)
+        th = [threading.Thread(target=r.close) for r in self.ranks]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
         for g in self.gpus:
             g.close()
+
+
+class LocalTileGroup(_TileGroup):
+    """LOCAL transport (csrc/tiles.hip): messages are device copies between the ranks' buffers, every exchange synchronises the
+    rank's stream and passes two host barriers of the whole group; kernels of one rank may store into a peer's planes (the
+    DIRECT protocol of the exact-order band split)."""
+
+    def __init__(self, nranks, rows=0, cols=0, halo=0, device=0):
+        _TileGroup.__init__(self, nranks, rows, cols, halo, device)
+        hs = (c_void_p * nranks)(*[g.h for g in self.gpus])
+        ts = (c_void_p * nranks)()
+        _chk(self.gpus[0].L.papof_tiles_create_local(hs, nranks, self.rows, self.cols, halo, ts), "papof_tiles_create_local")
+        self.ranks = [TileRank(g, c_void_p(t)) for g, t in zip(self.gpus, ts)]
+
+
+class RcclTileGroup(_TileGroup):
+    """The RCCL transport itself -- papof_tiles_create, one communicator rank per thread -- which is what one process per GPU
+    runs on a multi-GPU node.  On ONE device the real librccl refuses several ranks, so PAPOF_RCCL_LIB must name a library
+    with RCCL's API whose ranks may share a device: tests/fake_rccl (stream-ordered group kernels, no host synchronisation)."""
+
+    def __init__(self, nranks, rows=0, cols=0, halo=0, device=0):
+        import threading
+        _TileGroup.__init__(self, nranks, rows, cols, halo, device)
+        uid = tiles_unique_id()
+        made, errs = [None] * nranks, [None] * nranks
+
+        def init(r):  # ncclCommInitRank returns when every rank has called it
+            try:
+                made[r] = TileRank.create(self.gpus[r], uid, r, nranks, self.rows, self.cols, halo)
+            except Exception as e:  # noqa: BLE001
+                errs[r] = e
+        th = [threading.Thread(target=init, args=(r,)) for r in range(nranks)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        self.ranks = [m for m in made if m is not None]
+        for e in errs:
+            if e is not None:
+                self.close()
+                raise e

@@ -29,8 +29,10 @@
 #include <condition_variable>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is loaded at run time
@@ -116,6 +118,11 @@ struct Transport {
     // its producer).  Transports whose ranks own a device each need neither.
     virtual int turn_wait(int /*above*/, long /*solve*/) { return PAPOF_OK; }
     virtual void turn_done(long /*solve*/) {}
+    // Wait for everything this rank has enqueued on h->stream (the end of a call, a reallocation of the staging buffers).
+    virtual int drain(papof_handle* h) {
+        PAPOF_HIP(hipStreamSynchronize(h->stream));
+        return PAPOF_OK;
+    }
 };
 
 struct RcclApi {
@@ -123,6 +130,7 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclCommUserRank) CommUserRank = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -132,35 +140,50 @@ struct RcclApi {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
+// PAPOF_RCCL_LIB (read at every papof_tiles_unique_id / papof_tiles_create): another library with librccl's point-to-point API.
+// The tests hand in tests/fake_rccl/libfake_rccl.so -- the ranks of a group as threads of one process on one device, with
+// RCCL's semantics (a group is one kernel on the caller's stream, nothing waits on the host) -- so that THIS transport, the one
+// the multi-GPU node runs, is what the multi-rank parity tests exercise on a one-GPU box.  One table of entry points per path.
 const RcclApi* rccl() {
-    static RcclApi api;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        // the soname first: a process that already holds a librccl (PyTorch's) gets that very copy back
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        void* lib = nullptr;
-        for (const char* n : names)
-            if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-        if (!lib) return;
+    static std::mutex mu;
+    static std::map<std::string, RcclApi> apis;  // (node-based: pointers to the entries stay valid)
+    const char* const over = std::getenv("PAPOF_RCCL_LIB");
+    const std::string key = over && over[0] ? over : "";
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = apis.find(key);
+    if (it == apis.end()) {
         RcclApi a;
-        a.lib = lib;
+        void* lib = nullptr;
+        if (!key.empty()) {
+            lib = dlopen(key.c_str(), RTLD_NOW | RTLD_LOCAL);
+        } else {
+            // the soname first: a process that already holds a librccl (PyTorch's) gets that very copy back
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char* n : names)
+                if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        }
+        if (lib) {
+            a.lib = lib;
 #define PAPOF_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(lib, name))
-        PAPOF_SYM(GetUniqueId, "ncclGetUniqueId");
-        PAPOF_SYM(CommInitRank, "ncclCommInitRank");
-        PAPOF_SYM(CommDestroy, "ncclCommDestroy");
-        PAPOF_SYM(CommCount, "ncclCommCount");
-        PAPOF_SYM(CommUserRank, "ncclCommUserRank");
-        PAPOF_SYM(GroupStart, "ncclGroupStart");
-        PAPOF_SYM(GroupEnd, "ncclGroupEnd");
-        PAPOF_SYM(Send, "ncclSend");
-        PAPOF_SYM(Recv, "ncclRecv");
-        PAPOF_SYM(GetErrorString, "ncclGetErrorString");
+            PAPOF_SYM(GetUniqueId, "ncclGetUniqueId");
+            PAPOF_SYM(CommInitRank, "ncclCommInitRank");
+            PAPOF_SYM(CommDestroy, "ncclCommDestroy");
+            PAPOF_SYM(CommAbort, "ncclCommAbort");
+            PAPOF_SYM(CommCount, "ncclCommCount");
+            PAPOF_SYM(CommUserRank, "ncclCommUserRank");
+            PAPOF_SYM(GroupStart, "ncclGroupStart");
+            PAPOF_SYM(GroupEnd, "ncclGroupEnd");
+            PAPOF_SYM(Send, "ncclSend");
+            PAPOF_SYM(Recv, "ncclRecv");
+            PAPOF_SYM(GetErrorString, "ncclGetErrorString");
 #undef PAPOF_SYM
-        if (a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv &&
-            a.GetErrorString)
-            api = a;
-    });
-    return api.lib ? &api : nullptr;
+            if (!(a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv &&
+                  a.GetErrorString))
+                a.lib = nullptr;
+        }
+        it = apis.emplace(key, a).first;
+    }
+    return it->second.lib ? &it->second : nullptr;
 }
 
 #define PAPOF_NCCL(api, expr)                                                                    \
@@ -179,14 +202,43 @@ struct RcclTransport : Transport {
         if (comm) api->CommDestroy(comm);
     }
     int seen(int* n, int* r) const override {
-        if (!api->CommCount || !api->CommUserRank) return PAPOF_EDEVICE;
+        if (!api->CommCount || !api->CommUserRank || !comm) return PAPOF_EDEVICE;
         PAPOF_NCCL(api, api->CommCount(comm, n));
         PAPOF_NCCL(api, api->CommUserRank(comm, r));
         return PAPOF_OK;
     }
     int barrier(papof_handle*) override { return PAPOF_OK; }  // every rank writes only its own memory: nothing to order
+    // A receive whose peer never sends does not end by itself: the stream is polled against a deadline (PAPOF_TILES_TIMEOUT_S,
+    // default 120 s per call), and a rank that runs into it ABORTS its communicator (ncclCommAbort: the library's kernels in
+    // flight exit), drains what is left and reports PAPOF_ETIMEOUT.  The communicator is unusable afterwards, as RCCL defines.
+    bool aborted = false;
+    int drain(papof_handle* h) override {
+        const char* e = std::getenv("PAPOF_TILES_TIMEOUT_S");
+        const double limit = e && std::atof(e) > 0 ? std::atof(e) : 120.0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; spins++) {
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipSuccess) return aborted ? PAPOF_ETIMEOUT : PAPOF_OK;
+            if (q != hipErrorNotReady) {
+                set_last_error("hipStreamQuery", q, __FILE__, __LINE__);
+                return PAPOF_EDEVICE;
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) break;
+            if (spins < 2000)
+                std::this_thread::yield();
+            else
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        aborted = true;
+        set_last_error_text("a peer of the tile group did not answer within PAPOF_TILES_TIMEOUT_S: communicator aborted");
+        if (api->CommAbort) api->CommAbort(comm);
+        comm = nullptr;  // (ncclCommAbort frees it)
+        (void)hipStreamSynchronize(h->stream);  // without an abort entry point this waits for the library's own watchdog
+        return PAPOF_ETIMEOUT;
+    }
     int exchange(papof_handle* h, const std::vector<Msg>& sends, const std::vector<Msg>& recvs) override {
         if (sends.empty() && recvs.empty()) return PAPOF_OK;
+        if (aborted || !comm) return PAPOF_ETIMEOUT;
         PAPOF_NCCL(api, api->GroupStart());
         for (const Msg& m : sends) PAPOF_NCCL(api, api->Send(m.buf, m.count, ncclDouble, m.peer, comm, h->stream));
         for (const Msg& m : recvs) PAPOF_NCCL(api, api->Recv(m.buf, m.count, ncclDouble, m.peer, comm, h->stream));
@@ -354,35 +406,35 @@ struct papof_tiles {
     TileGrid grid{1, 1};
     int halo = 10;  // S: ghost-zone depth in half-sweeps
     std::unique_ptr<Transport> tp;
-    double *send_stage = nullptr, *recv_stage = nullptr;
+    double *send_stage = nullptr, *recv_stage = nullptr;  // inside the handle's arena, carved per call (stage_carve)
     size_t stage_cap = 0;  // doubles, each
     long exchanges = 0;    // statistics of the last call
     size_t exchanged_bytes = 0;
-    ~papof_tiles() {
-        if (h) hipSetDevice(h->device);
-        if (send_stage) hipFree(send_stage);
-        if (recv_stage) hipFree(recv_stage);
-    }
 };
 
 namespace papof {
 namespace {
 
-int ensure_stage(papof_tiles& t, size_t doubles) {
-    if (doubles <= t.stage_cap) return PAPOF_OK;
-    PAPOF_HIP(hipStreamSynchronize(t.h->stream));
-    if (t.send_stage) PAPOF_HIP(hipFree(t.send_stage));
-    if (t.recv_stage) PAPOF_HIP(hipFree(t.recv_stage));
-    t.send_stage = t.recv_stage = nullptr;
-    t.stage_cap = 0;
-    const size_t cap = doubles + doubles / 4 + 4096;
-    if (hipMalloc((void**)&t.send_stage, cap * sizeof(double)) != hipSuccess ||
-        hipMalloc((void**)&t.recv_stage, cap * sizeof(double)) != hipSuccess) {
-        set_last_error_text("hipMalloc(tile exchange staging) failed");
+// The packed messages of an exchange live in two buffers carved from the handle's ARENA at the start of every call
+// (stage_carve): nothing is allocated or freed while a call is in flight.  [Round 4: they used to be grown with hipFree /
+// hipMalloc in the middle of a call.  hipFree waits for the whole device; harmless with one rank per GPU but for the stall --
+// and a deadlock as soon as ranks share a device and a peer's receive waits on this rank's next launch, which is how the
+// RCCL stand-in of tests/fake_rccl found it.]
+size_t stage_doubles(int H, int W, int C) { return (size_t)H * W * (size_t)std::max(C, 2) + 4096; }  // the final gather is the largest message
+int stage_carve(papof_tiles& t, Arena& A, int H, int W, int C) {
+    t.stage_cap = stage_doubles(H, W, C);
+    t.send_stage = A.f64(t.stage_cap);
+    t.recv_stage = A.f64(t.stage_cap);
+    if (!t.send_stage || !t.recv_stage) {
+        t.stage_cap = 0;
         return PAPOF_ENOMEM;
     }
-    t.stage_cap = cap;
     return PAPOF_OK;
+}
+int ensure_stage(papof_tiles& t, size_t doubles) {
+    if (doubles <= t.stage_cap) return PAPOF_OK;
+    set_last_error_text("tile exchange: a message plan exceeds the staging buffers of the call");
+    return PAPOF_EINVAL;
 }
 
 using RectOf = std::function<Rect(int)>;
@@ -459,10 +511,12 @@ int tiles_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     PAPOF_TRY(pyramid_plan(H, W, P.ratio, levels, L, plan));
     const int n_sor_max = P.n_sor + (levels - 1) * P.n_sor_per_level;
     h->seq.valid = false;
-    PAPOF_TRY(ensure_arena(h, arena_bytes_for(H, W, C, levels, n_sor_max, P.ratio) + (size_t)H * W * C * sizeof(double)));
+    PAPOF_TRY(ensure_arena(h, arena_bytes_for(H, W, C, levels, n_sor_max, P.ratio) + (size_t)H * W * C * sizeof(double) +
+                              2 * (stage_doubles(H, W, C) + 64) * sizeof(double)));
     Arena& A = h->arena;
     A.off = 0;
     A.overflow = false;
+    PAPOF_TRY(stage_carve(t, A, H, W, C));
     h->events_used = 0;
     t.exchanges = 0;
     t.exchanged_bytes = 0;
@@ -657,7 +711,8 @@ int tiles_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
         }
     }
     total.phase(-1);
-    PAPOF_HIP(hipStreamSynchronize(h->stream));
+    PAPOF_TRY(t.tp->drain(h));
+    if (overlap) PAPOF_HIP(hipStreamSynchronize(h->prep_stream));
     if (total.err != PAPOF_OK || sorclk.err != PAPOF_OK) return PAPOF_EDEVICE;
     sorclk.collect(tm);
     total.collect(tm);
@@ -733,10 +788,12 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     PAPOF_TRY(pyramid_plan(H, W, P.ratio, levels, L, plan));
     h->seq.valid = false;
     PAPOF_TRY(ensure_arena(h, arena_bytes_for(H, W, C, levels, n_sor_max, P.ratio) + (size_t)H * W * C * sizeof(double) +
-                              (size_t)(t.tp->nranks + 2) * kLapMaxSlots * 8 * sizeof(unsigned)));  // + the guard's flags of all ranks
+                              (size_t)(t.tp->nranks + 2) * kLapMaxSlots * 8 * sizeof(unsigned) +  // + the guard's flags of all ranks
+                              2 * (stage_doubles(H, W, C) + 64) * sizeof(double)));
     Arena& A = h->arena;
     A.off = 0;
     A.overflow = false;
+    PAPOF_TRY(stage_carve(t, A, H, W, C));
     h->events_used = 0;
     h->sor_log.clear();
     t.exchanges = 0;
@@ -765,10 +822,15 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     // pair (values scaled to ~1e-21) belongs on the one-GPU call, which has the exact pass.
     long lap_slots = 0;
     for (int k = 0; k < levels; k++) lap_slots += P.n_outer + (long)k * P.n_outer_per_level;
-    const bool lap_on = h->lap_guard && fc <= 8 && lap_slots <= kLapMaxSlots / 2;
+    const bool lap_on = h->lap_guard;
+    if (lap_on && (fc > 8 || lap_slots > kLapMaxSlots / 2)) {  // it proves or refuses: never a call without the check
+        set_last_error_text("the band split cannot prove the reference's Laplacian-noise guard (src/OpticalFlow.cpp:399-400) for "
+                            "this channel count / number of outer iterations: run the pair on one GPU (papof_flow*)");
+        return PAPOF_EINVAL;
+    }
     const size_t lap_words = (size_t)std::max<long>(lap_slots, 1) * 16;       // per rank: 8 witness + 8 valid words per slot
-    unsigned* lap_mine = reinterpret_cast<unsigned*>(A.f64(lap_words / 2));   // [slot][0..7] witness, [slot][8..15] valid
-    unsigned* lap_all = reinterpret_cast<unsigned*>(A.f64(lap_words / 2 * (size_t)n));  // every rank's, by rank
+    unsigned* lap_mine = lap_on ? reinterpret_cast<unsigned*>(A.f64(lap_words / 2)) : nullptr;  // [slot][0..7] witness, [slot][8..15] valid
+    unsigned* lap_all = lap_on ? reinterpret_cast<unsigned*>(A.f64(lap_words / 2 * (size_t)n)) : nullptr;  // every rank's, by rank
     constexpr unsigned kLapSet = 1u;  // (the flags are cleared by every call: a set flag needs no pass number here)
     if (lap_on) PAPOF_HIP(hipMemsetAsync(lap_mine, 0, lap_words * sizeof(unsigned), h->stream));
     long lap_slot = 0;
@@ -986,7 +1048,7 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
                 if (mine && me == 0) PAPOF_TRY(solve_mine());
                 for (int r = 0; r + 1 < m_ranks; r++) {
                     std::vector<Msg> sends, recvs;
-                    if (me == r) {
+                    if (me == r && !silent) {  // (fault injection: a silent rank never sends its cut cells either)
                         hipLaunchKernelGGL(k_cut_cells<true>, cgrid, cblock, 0, h->stream, (double2*)outbox, (double2*)cutmsg,
                                            sp.sd.nb, npos, B1 - 1, K);
                         PAPOF_HIP(hipGetLastError());
@@ -1071,12 +1133,18 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
                 recvs.push_back(Msg{r, reinterpret_cast<double*>(lap_all + (size_t)r * lap_words), msg});
             }
         if (n > 1) PAPOF_TRY(t.tp->exchange(h, sends, recvs));
-        lap_host.resize(lap_words * (size_t)n);
-        PAPOF_HIP(hipMemcpyAsync(lap_host.data(), lap_all, lap_host.size() * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     }
     total.phase(-1);
-    PAPOF_HIP(hipStreamSynchronize(h->stream));
-    if (overlap) PAPOF_HIP(hipStreamSynchronize(h->prep_stream));
+    {   // the wait that a silent peer cannot hold for ever (Transport::drain) comes BEFORE anything that blocks the host on the
+        // stream -- a copy into pageable memory does, whatever its name says
+        const int rc_drain = t.tp->drain(h);
+        if (overlap) PAPOF_HIP(hipStreamSynchronize(h->prep_stream));
+        PAPOF_TRY(rc_drain);
+    }
+    if (lap_on) {
+        lap_host.resize(lap_words * (size_t)n);
+        PAPOF_HIP(hipMemcpy(lap_host.data(), lap_all, lap_host.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    }
     PAPOF_TRY(sor_check(h));  // PAPOF_ETIMEOUT when a bounded wait of this rank's tasks expired (a peer that never published)
     if (lap_on) {
         for (long s = 0; s + 1 < lap_slot; s++)  // the estimate behind the call's last update is never consulted

@@ -32,9 +32,9 @@ def _params(**kw):
     return default_params(**kw)
 
 
-def _run(nranks, a, b, levels, P):
+def _run(nranks, a, b, levels, P, group=None):
     from papteam_opticalflow_amd.capi import LocalTileGroup
-    grp = LocalTileGroup(nranks, nranks, 1, 0)
+    grp = (group or LocalTileGroup)(nranks, nranks, 1, 0)
     try:
         out = grp.coarse2fine_flow(a, b, levels, P)
         stats = grp.ranks[0].stats()
@@ -48,11 +48,12 @@ def _run(nranks, a, b, levels, P):
     ("cfg4_1920_L5", "1920", 5, dict(n_outer=3, n_outer_per_level=0, n_sor=30, n_sor_per_level=0)),
     ("e2e_960_L5", "960", 5, {}),
 ])
-def test_band_split_returns_the_reference_bits(case, res, levels, kw, nranks):
+def test_band_split_returns_the_reference_bits(case, res, levels, kw, nranks, tile_group):
     """whole calls with 2 and 8 ranks, array_equal to the reference's goldens: the SHA-256 of the
     full float64 arrays the untouched reference produced (golden.json), not only the strided subsample."""
     a, b = cases.load_pair(res)
-    (vx, vy, wi, t), (n_ex, n_bytes) = _run(nranks, a, b, levels, _params(**kw))
+    (vx, vy, wi, t), (n_ex, n_bytes) = _run(nranks, a, b, levels, _params(**kw), tile_group)
+    staged = tile_group.__name__ == "RcclTileGroup"  # no peer addressing: one cut message per solve and cut on top
     man = json.load(open(os.path.join(GOLD, "golden.json")))["cases"][case]
     gold = np.load(os.path.join(GOLD, "golden.npz"))
     for name, got in (("vx", vx), ("vy", vy), ("warpI2", wi)):
@@ -60,7 +61,10 @@ def test_band_split_returns_the_reference_bits(case, res, levels, kw, nranks):
             "%s/%s: max-abs %.3e vs the reference's subsample" % (case, name, np.abs(cases.subsample(got) - gold["%s|%s" % (case, name)]).max())
         assert cases.sha(got) == man[name]["sha"], "%s/%s: full-array SHA-256 differs from the reference's" % (case, name)
     n_solves = sum((kw.get("n_outer", 7) + k * kw.get("n_outer_per_level", 1)) for k in range(levels))
-    assert n_ex == n_solves + (levels - 1) + 2  # one (u, v) exchange per outer iteration, level changes, the final gather
+    if not staged:
+        assert n_ex == n_solves + (levels - 1) + 2  # one (u, v) exchange per outer iteration, level changes, the final gather
+    else:
+        assert n_ex > n_solves + (levels - 1) + 2
     assert t[9] > 0 and t[6] > 0
     print("exact-order band split, %d ranks, %s: %d exchanges, %.1f MB moved by rank 0, SOR %.2f ms of %.2f ms on one device" %
           (nranks, case, n_ex, n_bytes / 1e6, t[6] * 1e3, t[9] * 1e3))
@@ -73,21 +77,22 @@ def test_band_split_returns_the_reference_bits(case, res, levels, kw, nranks):
     (2, "480", 5, dict(n_outer=3, n_outer_per_level=0, n_sor=30, n_sor_per_level=0, alpha=0.02, omega=1.5)),
     (1, "240", 3, {}),
 ])
-def test_band_split_equals_one_gpu_exact_call(gpu, nranks, res, levels, kw):
+def test_band_split_equals_one_gpu_exact_call(gpu, tile_group, request, nranks, res, levels, kw):
+    request.node._standin_may_be_idle = nranks == 1
     a, b = cases.load_pair(res)
     P = _params(**kw)
     want = gpu.coarse2fine_flow(a, b, levels, P)[:3]
-    (vx, vy, wi, _), _ = _run(nranks, a, b, levels, P)
+    (vx, vy, wi, _), _ = _run(nranks, a, b, levels, P, tile_group)
     for name, g, w in zip(("vx", "vy", "warpI2"), (vx, vy, wi), want):
         assert np.array_equal(g, w), "%d ranks %s L%d %s %s: max-abs %.3e" % (nranks, res, levels, kw, name, np.abs(g - w).max())
 
 
-def test_band_split_ragged_frame_matches_oracle(oracle):
+def test_band_split_ragged_frame_matches_oracle(oracle, tile_group):
     a, b = cases.load_pair("480")
     a = np.ascontiguousarray(a[:203, :311])
     b = np.ascontiguousarray(b[:203, :311])
     kw = dict(n_outer=2, n_outer_per_level=1, n_sor=11, n_sor_per_level=2)
-    (vx, vy, wi, _), _ = _run(4, a, b, 3, _params(**kw))
+    (vx, vy, wi, _), _ = _run(4, a, b, 3, _params(**kw), tile_group)
     p = oracle.default_params()
     for k, v in kw.items():
         setattr(p, k, v)
@@ -147,7 +152,7 @@ def test_band_split_rejects_what_it_does_not_cover(gpu):
 
 
 @pytest.mark.parametrize("nranks", [2, 3])
-def test_band_split_proves_the_laplacian_noise_guard_or_refuses(gpu, nranks):
+def test_band_split_proves_the_laplacian_noise_guard_or_refuses(gpu, tile_group, nranks):
     """The band split runs without the noise estimate, so it must PROVE that the reference's `LapPara < 1E-20` guard
     (src/OpticalFlow.cpp:399-400) cannot have tripped -- every rank checks every pixel of its rows behind every update, the
     flags of all ranks are gathered -- or refuse the pair.  Ordinary frames: proven (the other tests of this file).  Duplicate
@@ -156,12 +161,12 @@ def test_band_split_proves_the_laplacian_noise_guard_or_refuses(gpu, nranks):
     from papteam_opticalflow_amd import PapofError
     a, b = cases.load_pair("240")
     P = _params()
-    (vx, vy, wi, _), _ = _run(nranks, a, a, 3, P)
+    (vx, vy, wi, _), _ = _run(nranks, a, a, 3, P, tile_group)
     want = gpu.coarse2fine_flow(a, a, 3, P)
     assert np.array_equal(vx, want[0]) and np.array_equal(vy, want[1]) and np.array_equal(wi, want[2])
     assert not vx.any() and not vy.any()
     with pytest.raises(PapofError) as e:
-        _run(nranks, np.ascontiguousarray(a * 1e-21), np.ascontiguousarray(b * 1e-21), 3, P)
+        _run(nranks, np.ascontiguousarray(a * 1e-21), np.ascontiguousarray(b * 1e-21), 3, P, tile_group)
     assert "guard" in str(e.value) and "one GPU" in str(e.value)
 
 
@@ -184,8 +189,35 @@ def test_a_peer_that_never_publishes_ends_in_a_timeout_not_a_hang(monkeypatch):
     assert np.isfinite(vx).all()
 
 
+def test_a_silent_peer_on_the_rccl_transport_ends_in_a_timeout_not_a_hang(monkeypatch, tile_group, request):
+    """The same fault on the transport the multi-GPU node runs (staged protocol: the cut cells of a solve travel as one message
+    behind the producer's kernel).  Rank 0 neither launches its solver kernels nor sends its cut cells; the receive of rank 1 is a
+    kernel on its stream that nothing will ever complete.  The call's final wait polls the stream against PAPOF_TILES_TIMEOUT_S,
+    aborts the communicator (ncclCommAbort: the library's kernels in flight exit) and returns PAPOF_ETIMEOUT on every rank --
+    rank 0 runs into the same deadline in its next exchange with the rank that gave up.  A new group works afterwards."""
+    import time
+    from papteam_opticalflow_amd import PapofError
+    if tile_group.__name__ != "RcclTileGroup":
+        pytest.skip("the LOCAL transport's variant is test_a_peer_that_never_publishes_ends_in_a_timeout_not_a_hang")
+    request.node._standin_errors_expected = True  # the missing send shifts the later messages of that pair: the stand-in objects
+    a, b = cases.load_pair("480")
+    P = _params(n_outer=1, n_outer_per_level=0, n_sor=5, n_sor_per_level=0)
+    monkeypatch.setenv("PAPOF_BANDS_SILENT_RANK", "0")
+    monkeypatch.setenv("PAPOF_TILES_TIMEOUT_S", "4")
+    t0 = time.time()
+    with pytest.raises(PapofError) as err:
+        _run(2, a, b, 1, P, tile_group)
+    assert err.value.code == -5, err.value
+    assert time.time() - t0 < 60
+    monkeypatch.delenv("PAPOF_BANDS_SILENT_RANK")
+    monkeypatch.delenv("PAPOF_TILES_TIMEOUT_S")
+    (vx, vy, wi, _), _ = _run(2, a, b, 1, P, tile_group)
+    want, _ = _run(2, a, b, 1, P)
+    assert np.array_equal(vx, want[0]) and np.array_equal(vy, want[1])
+
+
 @pytest.mark.parametrize("seed", range(3))
-def test_band_split_random_shapes_ranks_and_schedules(gpu, seed):
+def test_band_split_random_shapes_ranks_and_schedules(gpu, tile_group, seed):
     """Random frame sizes (one to five solver bands), rank counts (more ranks than bands included), pyramid depths and schedules:
     the split returns the bits of the one-GPU exact call."""
     rng = np.random.default_rng(3000 + seed)
@@ -199,6 +231,6 @@ def test_band_split_random_shapes_ranks_and_schedules(gpu, seed):
                   n_sor_per_level=int(rng.integers(0, 3)))
         print("seed %d case %d: %dx%d L%d ranks %d %s" % (seed, case, h, w, levels, nranks, kw), flush=True)
         P = _params(**kw)
-        (vx, vy, wi, _), _ = _run(nranks, a, b, levels, P)
+        (vx, vy, wi, _), _ = _run(nranks, a, b, levels, P, tile_group)
         want = gpu.coarse2fine_flow(a, b, levels, P)
         assert np.array_equal(vx, want[0]) and np.array_equal(vy, want[1]) and np.array_equal(wi, want[2]), (seed, case)

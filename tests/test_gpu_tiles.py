@@ -25,9 +25,9 @@ def _params(**kw):
     return default_params(**kw)
 
 
-def _run_tiles(nranks, rows, cols, halo, a, b, levels, P):
+def _run_tiles(nranks, rows, cols, halo, a, b, levels, P, group=None):
     from papteam_opticalflow_amd.capi import LocalTileGroup
-    grp = LocalTileGroup(nranks, rows, cols, halo)
+    grp = (group or LocalTileGroup)(nranks, rows, cols, halo)
     try:
         out = grp.coarse2fine_flow(a, b, levels, P)
         stats = grp.ranks[0].stats()
@@ -40,11 +40,11 @@ def _run_tiles(nranks, rows, cols, halo, a, b, levels, P):
     ("240", 3, 1, 2, 4), ("240", 5, 2, 2, 10), ("240", 4, 2, 4, 6), ("240", 3, 3, 1, 1), ("480", 5, 2, 4, 10),
     ("240", 2, 1, 3, 7),
 ])
-def test_tiled_equals_single_gpu_redblack(gpu, res, levels, rows, cols, halo):
+def test_tiled_equals_single_gpu_redblack(gpu, tile_group, res, levels, rows, cols, halo):
     a, b = cases.load_pair(res)
     P = _params()
     want = gpu.coarse2fine_flow(a, b, levels, P)[:3]
-    (vx, vy, wi, t), (n_ex, n_bytes) = _run_tiles(rows * cols, rows, cols, halo, a, b, levels, P)
+    (vx, vy, wi, t), (n_ex, n_bytes) = _run_tiles(rows * cols, rows, cols, halo, a, b, levels, P, tile_group)
     for name, g, w in zip(("vx", "vy", "warpI2"), (vx, vy, wi), want):
         assert np.array_equal(g, w), "%s differs: max-abs %.3e" % (name, np.abs(g - w).max())
     assert t[9] > 0 and t[6] > 0 and n_ex > 0 and n_bytes > 0
@@ -70,12 +70,12 @@ def test_tiled_ragged_sizes_and_schedule(gpu, oracle):
         assert np.abs(g - w).max() <= 1e-9, name
 
 
-def test_tiled_2x4_matches_the_oracle_itself(gpu, oracle):
+def test_tiled_2x4_matches_the_oracle_itself(gpu, oracle, tile_group):
     """BASELINE.json configs[4] geometry (2 x 4 tiles, LOCAL transport) compared with the ORACLE run in the same
     (red-black) mode -- not only with the one-GPU result: 480x270 pair, config-4 schedule (3 outer / 30 sweeps), 5 levels."""
     a, b = cases.load_pair("480")
     kw = dict(n_outer=3, n_outer_per_level=0, n_sor=30, n_sor_per_level=0)
-    (vx, vy, wi, _), _ = _run_tiles(8, 2, 4, 10, a, b, 5, _params(**kw))
+    (vx, vy, wi, _), _ = _run_tiles(8, 2, 4, 10, a, b, 5, _params(**kw), tile_group)
     p = oracle.default_params()
     for k, v in dict(kw, sor_mode=1).items():
         setattr(p, k, v)
@@ -95,7 +95,7 @@ def test_tiled_config4_schedule_full_hd_tile_grid(gpu):
     assert n_ex == 15 * (5 + 1) + 4 + 2  # per solve: 60 half-sweeps / 10 - 1 exchanges + (u, v); level changes; gather
 
 
-def test_config5_1920x1080_2x4_tiles_at_size(gpu, oracle):
+def test_config5_1920x1080_2x4_tiles_at_size(gpu, oracle, tile_group):
     """BASELINE.json configs[4] AT ITS SIZE, as far as one GPU allows: the 1920x1080 pair, 5 levels, config-4 schedule
     (3 outer / 30 SOR), sharded as 2 x 4 tiles with ghost zones 10 half-sweeps deep -- the eight ranks are threads of this
     process on one device (LOCAL transport: device copies where the multi-GPU run has RCCL sends; orchestration, regions,
@@ -105,7 +105,7 @@ def test_config5_1920x1080_2x4_tiles_at_size(gpu, oracle):
     a, b = cases.load_pair("1920")
     kw = dict(n_outer=3, n_outer_per_level=0, n_sor=30, n_sor_per_level=0)
     P = _params(**kw)
-    (vx, vy, wi, t), (n_ex, n_bytes) = _run_tiles(8, 2, 4, 10, a, b, 5, P)
+    (vx, vy, wi, t), (n_ex, n_bytes) = _run_tiles(8, 2, 4, 10, a, b, 5, P, tile_group)
     want = gpu.coarse2fine_flow(a, b, 5, P)[:3]
     for name, g, w in zip(("vx", "vy", "warpI2"), (vx, vy, wi), want):
         assert np.array_equal(g, w), "%s differs from the one-GPU red-black call: max-abs %.3e" % (name, np.abs(g - w).max())
@@ -184,7 +184,7 @@ def test_bench_tiles_reporting_path_single_rank():
 
 
 @pytest.mark.parametrize("seed", range(3))
-def test_tiles_random_grids_halos_and_shapes(gpu, seed):
+def test_tiles_random_grids_halos_and_shapes(gpu, tile_group, seed):
     """Random frame sizes, tile grids, ghost-zone depths, pyramid depths and schedules: whatever the tiled path accepts must be
     bit-identical to the one-GPU red-black call (a grid it refuses is refused with PAPOF_EINVAL, not computed wrongly)."""
     from papteam_opticalflow_amd import PapofError
@@ -202,7 +202,7 @@ def test_tiles_random_grids_halos_and_shapes(gpu, seed):
         print("seed %d case %d: %dx%d L%d grid %dx%d halo %d %s" % (seed, case, h, w, levels, rows, cols, halo, kw), flush=True)
         P = _params(**kw)
         try:
-            (vx, vy, wi, _), _ = _run_tiles(rows * cols, rows, cols, halo, a, b, levels, P)
+            (vx, vy, wi, _), _ = _run_tiles(rows * cols, rows, cols, halo, a, b, levels, P, tile_group)
         except PapofError as e:
             assert e.code == -1, e  # PAPOF_EINVAL: a grid / halo the path does not take
             continue
