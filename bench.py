@@ -410,7 +410,7 @@ def main():
                          "achieved": round(v["gbytes"] / v["sec"], 1), "frac": round(v["gbytes"] / v["sec"] / HBM_PEAK_GBS, 4)}
                      for n, v in by_kernel.items()}
         # parity statistic of the metric: max-abs delta (u, v) against the untouched reference's golden values
-        parity = None
+        parity, full_sha_equal = None, None
         try:
             import cases
             gold = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
@@ -423,6 +423,9 @@ def main():
                 gpu.dev_download(vy, dvy)
                 parity = float(max(np.abs(cases.subsample(vx) - gold[key + "|vx"]).max(),
                                    np.abs(cases.subsample(vy) - gold[key + "|vy"]).max()))
+                # every value, not the strided subsample: SHA-256 of the full arrays the untouched reference produced
+                man = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["cases"][key]
+                full_sha_equal = bool(cases.sha(vx) == man["vx"]["sha"] and cases.sha(vy) == man["vy"]["sha"])
         except Exception:
             parity = None
         out = {
@@ -440,7 +443,7 @@ def main():
                                    "PCIe transfers and all ten timers -- is value_call_inclusive on this same line",
                        "pairs_in_flight_per_gpu": args.pairs,
                        "parallelism": "replicas: one independent frame pair per GPU" if world > 1 else "1 GPU"},
-            "max_abs_duv_vs_reference": parity,
+            "max_abs_duv_vs_reference": parity, "full_sha_equal": full_sha_equal,
             "roofline": {"bound": "hbm", "kernel": "k_sor_exact + k_sor_fused (exact-order SOR solves)" if mode == 0 else
                          "k_sor_blocked (LDS-tiled, temporally blocked %s solves; %s %s per launch by level)" % (
                              args.mode, "/".join(str(d) for d in depths), "half-sweeps" if mode == 1 else "sweeps"),

@@ -1234,12 +1234,15 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
     lg.flags = h->lap_flags_dev;
     lg.lap = h->lap_dev;
     lg.scratch = h->lap_scratch_dev;
-    lg.nz_known = (size_t)levels * 8 <= (size_t)kLapNzWords;
+    // the non-zero flags of the feature channels are written by im2feature's 1- and 3-channel branches only (any other channel
+    // count is passed through untouched, src/OpticalFlow.cpp:956-960): without them no channel may count as "all zero"
+    lg.nz_known = (C == 1 || C == 3) && (size_t)levels * 8 <= (size_t)kLapNzWords;
     // inside a hipGraph nobody could act on the flags, and the bicubic branch has no sampled warp: always the exact pass
     const bool always_exact = h->use_graph || P.interpolation == PAPOF_INTERP_BICUBIC;
     lg.collect = !always_exact;
     lg.exact = always_exact || h->lap_exact;
     const papof_handle::Seq seq0 = h->seq;
+    double first_pass_total = 0.0;
     for (int pass = 0; pass < 2; pass++) {
         // a flag is set when it holds the number of the pass that wrote it: no clearing, nothing stale can be taken for a proof
         if (++h->lap_epoch >= kLapNone) {  // (2^31 passes later: start over on cleared flags)
@@ -1251,6 +1254,7 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         lg.slot_level.clear();
         lg.slot_channels.clear();
         PAPOF_TRY(flow_pass(h, fa, fb, op, H, W, C, levels, P, d_vx, d_vy, d_warp, timing, &lg));
+        if (pass == 1 && timing) timing[PAPOF_T_TOTAL] += first_pass_total;  // the call cost both passes (phases: the exact pass's)
         if (!lg.collect) return PAPOF_OK;
         const int unknown = lg.unknown(h->lap_flags_host);
         if (lg.exact) {  // the exact pass is right whatever the flags say; they decide how the NEXT call starts
@@ -1263,6 +1267,10 @@ int flow_device(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op,
         // already (host uploads of the first pass), the kept pyramid of a sequence is where it was.
         h->lap_reruns++;
         lg.exact = true;
+        if (timing) first_pass_total = timing[PAPOF_T_TOTAL];
+        // the first pass may have queued early result copies on the copy stream (HostIO): they must have left the device
+        // buffers before the second pass rewrites them
+        if (h->copy_stream) PAPOF_HIP(hipStreamSynchronize(h->copy_stream));
         h->seq = seq0;
         h->hostio.im1 = nullptr;
         h->hostio.im2 = nullptr;

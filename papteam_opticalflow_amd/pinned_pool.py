@@ -50,7 +50,11 @@ class PinnedPool(object):
         self._idle = {}              # class size -> [(tick, address), ...] oldest first
         self._tick = 0
         self._closed = False
+        # give_back() runs from a result array's __del__, which the cyclic GC may call while take() holds the lock ON THIS VERY
+        # THREAD (take() allocates Python objects): it never blocks -- a block it cannot book at once is parked in _deferred
+        # (list.append is atomic) and booked by whoever holds the lock next
         self._lock = threading.Lock()
+        self._deferred = []
         if register_atexit:
             atexit.register(self.drain)
 
@@ -72,6 +76,7 @@ class PinnedPool(object):
         pool drained): the caller then uses ordinary memory."""
         cls = size_class(nbytes)
         with self._lock:
+            self._book_deferred()
             if self._closed or cls > self.budget:
                 return None
             lst = self._idle.get(cls)
@@ -89,23 +94,39 @@ class PinnedPool(object):
             self.live_bytes += cls
             return addr, cls
 
+    def _book(self, addr, cls):
+        """(lock held) a block comes back: keep it idle, or free it"""
+        self.live_bytes -= cls
+        if self._closed:
+            return  # after drain(): the runtime may be gone, the process is ending -- drop, do not call into it
+        lst = self._idle.setdefault(cls, [])
+        if len(lst) >= self.max_idle:
+            self._free(addr)
+            return
+        self._tick += 1
+        lst.append((self._tick, addr))
+        self.idle_bytes += cls
+        self._evict_lru(0)
+
+    def _book_deferred(self):
+        while self._deferred:
+            addr, cls = self._deferred.pop()
+            self._book(addr, cls)
+
     def give_back(self, addr, cls):
-        with self._lock:
-            self.live_bytes -= cls
-            if self._closed:
-                return  # after drain(): the runtime may be gone, the process is ending -- drop, do not call into it
-            lst = self._idle.setdefault(cls, [])
-            if len(lst) >= self.max_idle:
-                self._free(addr)
-                return
-            self._tick += 1
-            lst.append((self._tick, addr))
-            self.idle_bytes += cls
-            self._evict_lru(0)
+        if not self._lock.acquire(blocking=False):
+            self._deferred.append((addr, cls))
+            return
+        try:
+            self._book(addr, cls)
+            self._book_deferred()
+        finally:
+            self._lock.release()
 
     def drain(self):
         """free every idle block and stop pooling (atexit; also callable by a host that wants the memory back)"""
         with self._lock:
+            self._book_deferred()
             if self._closed:
                 return
             self._closed = True

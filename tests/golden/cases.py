@@ -181,8 +181,9 @@ def lapguard_inputs():
     estLaplacianNoise, :594-639) TRIPS: channels 0, 1, 2, 4 are the same constant in both frames (every |Im1 - warpIm2| is
     exactly 0 there: no valid sample, LapPara = 0.001), channel 3 is a 1e-9-sized pattern that differs between the frames by
     ~1e-21 per sample -- so after the first outer iteration LapPara[3] ~ 1e-21 < 1e-20 and the guard skips channel 3's psi
-    from the second iteration on (the value of the first iteration stays in Psi_1st).  With alpha = 1e-20 the data term of
-    that one channel decides the result, so a restatement that zeroes a skipped psi gives other numbers."""
+    from the second iteration on: `Psi_1st.reset()` at the top of every inner iteration (:333-334) has zeroed it, so a skipped psi
+    IS 0 and that channel drops out of the linear system.  With alpha = 1e-20 the data term of that one channel decides the
+    result, so a restatement that keeps a skipped channel's psi (or never skips) gives other numbers."""
     rng = np.random.default_rng(21)
     h, w = 40, 56
     pat = 1.0 + 0.4 * np.tanh(smooth_field(rng, h, w, 1.0))

@@ -253,9 +253,13 @@ def test_end_to_end_matches_reference_golden(gpu, case):
     """Directly against the values the untouched reference produced (strided subsample in golden.npz),
     including the full-size 1920x1080 configurations of BASELINE.json that the oracle would need a minute for."""
     gold = np.load(os.path.join(GOLD, "golden.npz"))
+    man = json.load(open(os.path.join(GOLD, "golden.json")))["cases"][case]
     got = cases.CASES[case](gpu)
     for k, a in got.items():
         _cmp(case + "/" + k + " vs reference", cases.subsample(a), gold["%s|%s" % (case, k)], TOL_SOLVE)
+        # ... and EVERY value: the SHA-256 of the full float64 array the untouched reference produced (the subsample is 1 % of a
+        # 1080p plane and cannot see a defect confined to one band seam or column)
+        assert cases.sha(a) == man[k]["sha"], "%s/%s: full-array SHA-256 differs from the reference's" % (case, k)
 
 
 @pytest.mark.parametrize("h,w,levels,kw", [
@@ -696,6 +700,28 @@ def test_laplacian_noise_guard_whole_call_rerun_and_sticky_exact_pass(oracle):
         assert g.lap_guard_stats() == dict(reruns=1, exact_calls=2, exact_next=False, guard_on=True)
         for x, w in zip(first, second):
             assert np.array_equal(x, w)
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("c", [2, 4])
+def test_laplacian_noise_guard_on_pass_through_channel_counts(oracle, c):
+    """frames with 2 or 4..8 channels take im2feature's pass-through branch (src/OpticalFlow.cpp:956-960), which
+    writes no non-zero flags -- so no channel may be taken for "all zero" (a false proof).  A tripping pair of such frames must be
+    run again in the exact pass and agree with the oracle (parity for these channel counts is pinned by no reference golden:
+    the oracle restates the branch)."""
+    from papteam_opticalflow_amd import Papof
+    a, b = _tiny_scale_pair()
+    a = np.ascontiguousarray(np.concatenate([a, a[..., :1]], axis=2)[..., :c])
+    b = np.ascontiguousarray(np.concatenate([b, b[..., :1]], axis=2)[..., :c])
+    want = oracle.coarse2fine_flow(a, b, 3)[:3]
+    g = Papof(0)
+    try:
+        got = g.coarse2fine_flow(a, b, 3)[:3]
+        st = g.lap_guard_stats()
+        assert st["reruns"] == 1 and st["exact_next"] is True, st
+        for name, x, w in zip(("vx", "vy", "warpI2"), got, want):
+            assert _rel(x, w) <= 1e-9, "%d channels, %s: relative difference %.3e" % (c, name, _rel(x, w))
     finally:
         g.close()
 

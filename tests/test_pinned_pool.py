@@ -88,3 +88,28 @@ def test_idle_cap_per_class_and_drain():
     assert len(st.freed) == n_free and pool.live_bytes == 0
     pool.reopen()
     assert pool.take(8 * MB) is not None
+
+
+def test_give_back_from_inside_take_does_not_deadlock():
+    """a result array collected by the cyclic GC while take() holds the pool's lock on the same thread calls
+    give_back() from its __del__.  Modelled by an allocator that gives a block back while take() is running: the block is
+    parked, booked by the next call, and nothing blocks."""
+    from papteam_opticalflow_amd.pinned_pool import PinnedPool, size_class
+    freed, pool_box = [], {}
+    cls = size_class(1 << 20)
+
+    def alloc(n):
+        if pool_box.get("pending"):
+            pool_box["pool"].give_back(*pool_box.pop("pending"))  # re-entrant: the lock is held by take() right now
+        return 0x1000 + len(freed) * 0x100 + n % 7 + 1
+
+    pool = PinnedPool(alloc, freed.append, budget_bytes=64 << 20, register_atexit=False)
+    pool_box["pool"] = pool
+    first = pool.take(1 << 20)
+    assert first is not None and pool.live_bytes == cls
+    pool_box["pending"] = first
+    second = pool.take(2 << 20)          # alloc() runs inside the lock and gives `first` back
+    assert second is not None
+    third = pool.take(1 << 20)           # books the parked block first, then reuses it
+    assert third is not None and third[0] == first[0]
+    assert pool.live_bytes == second[1] + cls and pool.idle_bytes == 0
