@@ -525,9 +525,10 @@ def main():
                 npairs = 24 if nfl <= 4 else 6 * nfl
                 video = [a8, b8] * (npairs // 2) + [a8]
                 seen = []
-                flow_collection(video[:2 * nfl + 1], args.levels, in_flight=nfl, device=local_rank, on_pair=lambda i, *r: None, **kw)
+                flow_collection(video[:2 * nfl + 1], args.levels, in_flight=nfl, device=local_rank, batch=0,
+                                on_pair=lambda i, *r: None, **kw)
                 th = time.perf_counter()
-                flow_collection(video, args.levels, in_flight=nfl, device=local_rank,
+                flow_collection(video, args.levels, in_flight=nfl, device=local_rank, batch=0,
                                 on_pair=lambda i, t_, vx_, vy_, w_: seen.append(i), **kw)
                 dt = time.perf_counter() - th
                 assert sorted(seen) == list(range(npairs))
@@ -536,6 +537,25 @@ def main():
                     "value": round(npairs * h * w / 1e6 / dt, 2), "unit": "Mpix/s",
                     "note": "flow_collection(): host uint8 frames in, float64 results out into reused arrays (PCIe-inclusive), "
                             "one stream per handle"}
+                # small frames (the reference's own test matrix): the pairs of a collection share every launch of a chain
+                # (papof_flow_batch*, csrc/batch.hip) -- flow_collection()'s default there
+                from papteam_opticalflow_amd import collection_batch
+                nb_ = collection_batch(h, w)
+                if nb_ > 1 and mode == 0:
+                    npairs = 6 * nb_
+                    video = [a8, b8] * (npairs // 2) + [a8]
+                    seen = []
+                    flow_collection(video, args.levels, device=local_rank, batch=nb_, on_pair=lambda i, *r: None, **kw)
+                    th = time.perf_counter()
+                    flow_collection(video, args.levels, device=local_rank, batch=nb_,
+                                    on_pair=lambda i, t_, vx_, vy_, w_: seen.append(i), **kw)
+                    dt = time.perf_counter() - th
+                    assert sorted(seen) == list(range(npairs))
+                    out["collection_u8_batches_of_%d" % nb_] = {
+                        "pairs": npairs, "batch": nb_, "chains_in_flight": 2, "ms_per_pair": round(dt / npairs * 1e3, 3),
+                        "value": round(npairs * h * w / 1e6 / dt, 2), "unit": "Mpix/s",
+                        "note": "flow_collection(batch=%d): %d consecutive pairs per launch chain (papof_flow_batch_u8), host uint8 "
+                                "frames in, float64 results out (PCIe-inclusive); every pair bit-identical to the single call" % (nb_, nb_)}
             except StopIteration:
                 pass
             except Exception as e:  # noqa: BLE001 -- secondary figures only

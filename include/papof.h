@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PAPOF_VERSION 104 /* 0.1.4: the Laplacian-noise guard (papof_lap_guard_stats); 0.1.3: papof_last_sor_solves, exact-order band split over ranks (papof_tiles_*, PAPOF_SOR_EXACT); 0.1.2: measurement / test aids (papof_last_sor_stats, papof_strip_plan, papof_test_sor_strips); 0.1.1: papof_params gained interpolation / noise_model */
+#define PAPOF_VERSION 105 /* 0.1.5: papof_flow_batch / papof_flow_batch_u8, papof_last_host_times, PAPOF_RCCL_LIB / PAPOF_TILES_TIMEOUT_S; 0.1.4: the Laplacian-noise guard (papof_lap_guard_stats); 0.1.3: papof_last_sor_solves, exact-order band split over ranks (papof_tiles_*, PAPOF_SOR_EXACT); 0.1.2: measurement / test aids (papof_last_sor_stats, papof_strip_plan, papof_test_sor_strips); 0.1.1: papof_params gained interpolation / noise_model */
 
 enum {
     PAPOF_OK = 0,
@@ -357,6 +357,30 @@ int papof_last_sor_solves(papof_handle* h, int cap, int* n, int* info, double* s
  * all ranks are gathered) or returns PAPOF_EINVAL on every rank with a message that names the one-GPU call; the red-black
  * tiles -- not the reference's sweep order anyway -- run without the guard. */
 int papof_lap_guard_stats(papof_handle* h, int out[4]);
+
+/* B = n_pairs frame pairs of ONE shape in ONE launch chain (csrc/batch.hip) -- the reference's benchmark walks collections of
+ * small frames (Code/Serial/TestSuite.py:69-81: 101 pairs per collection; :91: 240x135 ... 1920x1080), and a 240x135 pair
+ * alone is ~210 launches of a few microseconds each: here every launch serves all pairs of the batch.  Host buffers in and out,
+ * as papof_flow / papof_flow_u8.  sequence != 0: pair i = (frames[i], frames[i + 1]), n_pairs + 1 frames -- a video; every
+ * frame's pyramid and features are built once.  sequence == 0: pair i = (frames[2 i], frames[2 i + 1]), 2 n_pairs frames.
+ * vx[i], vy[i] (height x width) and warpI2[i] (height x width x c) receive pair i's results: bit-identical to
+ * papof_flow(frames of pair i).  timing_sec: Total = the caller's wall time of the batch, Phase5_SOR = the solver kernels' own
+ * time; the other phases are not separated in a batch.  What the batched chain covers: the default branches in the reference's
+ * own sweep order (PAPOF_SOR_EXACT, n_inner = 1, bilinear, Laplacian noise model), 1 or 3 channels, fewer than 16 solver
+ * bands per level (frames up to ~900 rows); anything else -- and n_pairs = 1 -- runs as consecutive single calls through this
+ * same entry point.  A pair whose Laplacian-noise guard (papof_lap_guard_stats) cannot be proven open in the batch is run again
+ * through the single call.  Any sequence kept by papof_seq_push* on the handle ends. */
+int papof_flow_batch(papof_handle* h, int n_pairs, int sequence, const double* const* frames, int height, int width, int c,
+                     int pyramid_levels, const papof_params* params, double* const* vx, double* const* vy,
+                     double* const* warpI2, double timing_sec[PAPOF_N_TIMERS]);
+int papof_flow_batch_u8(papof_handle* h, int n_pairs, int sequence, const unsigned char* const* frames, int height,
+                        int width, int c, int pyramid_levels, const papof_params* params, double* const* vx,
+                        double* const* vy, double* const* warpI2, double timing_sec[PAPOF_N_TIMERS]);
+
+/* Measurement aid (tools/collection_trace.py): host-side wall seconds of the LAST papof_flow* / papof_seq_push* call on this
+ * handle -- out[0] from the call's entry until everything was enqueued (the runtime's launch path: ~200 launches for a
+ * 240x135 pair on the reference schedule), out[1] the wait for the streams that followed, out[2] reserved (0). */
+int papof_last_host_times(papof_handle* h, double out[3]);
 
 /* Test aid: the strip schedule (api.hip: smooth_flow_strips) a level of height x width with `n_sor` sweeps and
  * `n_outer` outer iterations gets on this handle.  *strips = S (1: the level is not cut).  out, if not NULL, receives

@@ -128,7 +128,18 @@ def collection_in_flight(height, width):
     return 16 if mpix <= 0.3 else (8 if mpix <= 1.0 else 4)
 
 
-def flow_collection(frames, pyramidLevels, in_flight=None, device=None, on_pair=None, **solver):
+def collection_batch(height, width):
+    """Pairs per launch chain flow_collection() uses by default (0: unbatched): frames too small to fill the chip share every
+    launch (csrc/batch.hip) -- 240x135 on the reference schedule: 8.4 ms per single call, 2.0 ms per pair as 16 independent calls in
+    flight, ~0.9 ms per pair in batches of 16 (tools/batch_probe.py, profiles/r04_batch_probe_*.txt)."""
+    mpix = height * width / 1e6
+    # measured per pair, reference schedule, host uint8 in / float64 out (profiles/r04_batch_probe_*.txt, r04_collection_probe_*):
+    # 240x135: 8.4 ms alone, 2.2 as 16 calls in flight, 0.87 / 0.76 in batches of 16 / 32; 480x270: 11.8 / 3.25 / 2.2 in batches of
+    # 16; 960x540: 16.5 / 8.9 / 9.2 in batches of 8 -- from there on a pair fills enough of the chip by itself
+    return 32 if mpix <= 0.05 else (16 if mpix <= 0.14 else 0)
+
+
+def flow_collection(frames, pyramidLevels, in_flight=None, device=None, on_pair=None, batch=None, **solver):
     """Flow of every consecutive pair of a frame list -- what the reference's TestSuite does with a collection
     (Code/Serial/TestSuite.py:69-81: frame n -> n+1 for 101 pairs) -- with `in_flight` sequences running concurrently
     on one GPU (default: by frame size, collection_in_flight()): the list is cut into contiguous segments (overlapping by one frame), each pushed through its own
@@ -139,15 +150,24 @@ def flow_collection(frames, pyramidLevels, in_flight=None, device=None, on_pair=
     order) with arrays that are REUSED for the worker's next pair -- copy what you keep; nothing is returned.  This is
     the fast form: 83 MB of fresh result memory per 1080p pair costs more in page faults than the GPU takes to fill
     it.  Without on_pair the list of (timing, vx, vy, warpI2) in pair order is returned (fresh arrays).
-    Every result is bit-identical to coarse2fine_flow(frames[i], frames[i + 1], pyramidLevels)."""
+    Every result is bit-identical to coarse2fine_flow(frames[i], frames[i + 1], pyramidLevels).
+
+    batch: pairs per launch chain (default by frame size, collection_batch(); 0 / 1: every pair its own call).  Small frames
+    cannot fill the chip and are bound by the device's dispatch of their ~210 little dependent kernels per pair; in a batch
+    every launch serves all its pairs (include/papof.h: papof_flow_batch*).  With batch > 1 the ten timers of a pair are its
+    CHAIN's (Total = wall time of the chain, Phase5_SOR = its solver kernels)."""
     import threading
     import numpy as np
     capi.load()  # once, in this thread
     n_pairs = len(frames) - 1
     if n_pairs < 1:
         return None if on_pair else []
+    h0, w0 = np.shape(frames[0])[:2]
+    if batch is None:
+        batch = collection_batch(h0, w0)
+    if batch and batch > 1 and n_pairs > 1:
+        return _flow_collection_batched(frames, pyramidLevels, int(batch), in_flight, device, on_pair, solver)
     if in_flight is None:
-        h0, w0 = np.shape(frames[0])[:2]
         in_flight = collection_in_flight(h0, w0)
     k = max(1, min(int(in_flight), n_pairs))
     bounds = [n_pairs * s // k for s in range(k + 1)]  # segment s computes pairs bounds[s] .. bounds[s+1]-1
@@ -184,6 +204,55 @@ def flow_collection(frames, pyramidLevels, in_flight=None, device=None, on_pair=
         t.start()
     for t in threads:
         t.join()
+    if errors:
+        raise errors[0]
+    return None if on_pair else results
+
+
+def _flow_collection_batched(frames, levels, batch, in_flight, device, on_pair, solver):
+    """flow_collection() through papof_flow_batch*: the pairs of a collection in chains of `batch` consecutive pairs per launch
+    chain (a video: every frame's pyramid is built once per chain), `in_flight` chains at a time (default 2: one handle's uploads,
+    downloads and host work beside the other's kernels).  Bit-identical results, pair for pair."""
+    import os
+    import threading
+    n_pairs = len(frames) - 1
+    dev = int(os.environ.get("PAPOF_DEVICE", "0")) if device is None else int(device)
+    k = max(1, min(int(in_flight) if in_flight else 2, (n_pairs + batch - 1) // batch))
+    pool = _collection_handles.setdefault(dev, [])
+    while len(pool) < k:
+        pool.append(Papof(dev))
+    params = default_params(**solver) if solver else None
+    chains = [(i0, min(i0 + batch, n_pairs)) for i0 in range(0, n_pairs, batch)]
+    results, errors = [None] * n_pairs, []
+    lock = threading.Lock()
+    nxt = [0]
+
+    def run(s):
+        try:
+            out = None
+            while True:
+                with lock:
+                    if nxt[0] >= len(chains):
+                        return
+                    i0, i1 = chains[nxt[0]]
+                    nxt[0] += 1
+                reuse = out if (on_pair is not None and out is not None and len(out) == i1 - i0) else None
+                out, t = pool[s].flow_batch(frames[i0:i1 + 1], levels, params, sequence=True, out=reuse)
+                timing = capi.format_timing(t)
+                for j in range(i1 - i0):
+                    if on_pair is not None:
+                        on_pair(i0 + j, timing, *out[j])
+                    else:
+                        results[i0 + j] = (timing,) + tuple(out[j])
+                if on_pair is None:
+                    out = None  # the caller keeps these arrays
+        except Exception as e:  # noqa: BLE001 -- re-raised in the caller's thread
+            errors.append(e)
+    threads = [threading.Thread(target=run, args=(s,)) for s in range(k)]
+    for t_ in threads:
+        t_.start()
+    for t_ in threads:
+        t_.join()
     if errors:
         raise errors[0]
     return None if on_pair else results

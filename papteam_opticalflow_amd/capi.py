@@ -50,7 +50,8 @@ SYMBOLS = [
     "papof_flow_dequantize16", "papof_flow_to_bgr", "papof_set_graph_mode", "papof_set_stream_overlap", "papof_sor_plan", "papof_last_sor_stats", "papof_strip_plan", "papof_test_sor_strips",
     "papof_pyramid_levels_for_min_width", "papof_stage_smoothflow_ex", "papof_stage_est_gaussian_mixture",
     "papof_stage_bicubic_warp_ex", "papof_tiles_comm_info", "papof_host_alloc", "papof_host_free",
-    "papof_last_sor_solves", "papof_bands_plan", "papof_lap_guard_stats",
+    "papof_last_sor_solves", "papof_bands_plan", "papof_lap_guard_stats", "papof_last_host_times",
+    "papof_flow_batch", "papof_flow_batch_u8",
 ]
 
 
@@ -143,6 +144,10 @@ def load():
     L.papof_last_sor_solves.argtypes = [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                         ctypes.POINTER(ctypes.c_double)]
     L.papof_lap_guard_stats.argtypes = [c_void_p, ctypes.POINTER(c_int)]
+    L.papof_last_host_times.argtypes = [c_void_p, ctypes.POINTER(c_double)]
+    for fn in (L.papof_flow_batch, L.papof_flow_batch_u8):
+        fn.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, _D]
+        fn.restype = c_int
     L.papof_test_sor_strips.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                         ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(c_int)]
     L.papof_strip_plan.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int),
@@ -578,6 +583,43 @@ class Papof:
         _chk(self.L.papof_last_sor_solves(self.h, cap, ctypes.byref(n), info, sec), "papof_last_sor_solves")
         keys = ("h", "w", "n_sor", "kind", "depth", "launches")
         return [dict(zip(keys, info[6 * i:6 * i + 6]), sec=sec[i]) for i in range(min(cap, n.value))]
+
+    def flow_batch(self, frames, levels, params=None, sequence=True, out=None):
+        """B frame pairs of one shape in ONE launch chain (include/papof.h: papof_flow_batch*).  frames: a list of HWC arrays,
+        all float64 in [0, 1] or all uint8; sequence=True: pair i = (frames[i], frames[i + 1]); False: (frames[2i], frames[2i+1]).
+        Returns [(vx, vy, warpI2), ...] per pair (out: a list of such triples to be reused) and the ten timers of the batch.
+        Every pair's arrays are bit-identical to coarse2fine_flow(pair)."""
+        u8 = np.asarray(frames[0]).dtype == np.uint8
+        if isinstance(frames, np.ndarray) and frames.ndim == 4 and frames.flags["C_CONTIGUOUS"]:
+            fr = frames if u8 else np.ascontiguousarray(frames, dtype=np.float64)
+        else:
+            first = np.asarray(frames[0])
+            for f in frames:
+                if np.shape(f) != first.shape or first.ndim != 3:
+                    raise ValueError("all frames of a batch must have one H x W x C shape")
+            fr = np.stack([_u8(f) if u8 else _c(f, 3) for f in frames])  # one host block: one upload
+        h, w, c = fr[0].shape
+        n_pairs = len(fr) - 1 if sequence else len(fr) // 2
+        if n_pairs < 1 or (not sequence and len(fr) != 2 * n_pairs):
+            raise ValueError("a batch needs at least one pair (sequence: n + 1 frames, else 2 n)")
+        if out is None:  # one (page-locked) block per kind, laid out as the device's: the results come back as two copies
+            uv, wi = result_array((n_pairs, 2, h, w)), result_array((n_pairs, h, w, c))
+            out = [(uv[i, 0], uv[i, 1], wi[i]) for i in range(n_pairs)]
+        t = np.zeros(N_TIMERS)
+        PP = ctypes.c_void_p * len(fr)
+        fp = PP(*[f.ctypes.data for f in fr])
+        OP = ctypes.c_void_p * n_pairs
+        ox, oy, ow = (OP(*[o[i].ctypes.data for o in out]) for i in range(3))
+        pp = ctypes.byref(params) if params is not None else None
+        fn = self.L.papof_flow_batch_u8 if u8 else self.L.papof_flow_batch
+        _chk(fn(self.h, n_pairs, 1 if sequence else 0, fp, h, w, c, int(levels), pp, ox, oy, ow, _p(t)), "papof_flow_batch")
+        return out, t
+
+    def last_host_times(self):
+        """(enqueue_sec, wait_sec) of the last call on this handle: host wall time spent enqueueing / waiting for the streams"""
+        out = (c_double * 3)()
+        _chk(self.L.papof_last_host_times(self.h, out), "papof_last_host_times")
+        return out[0], out[1]
 
     def lap_guard_stats(self):
         """dict(reruns, exact_calls, exact_next, guard_on): the Laplacian-noise guard (include/papof.h: papof_lap_guard_stats)"""

@@ -657,6 +657,7 @@ bool seq_matches(const papof_handle* h, int H, int W, int C, int levels, double 
 // The whole call on device-resident buffers: ONE pass (flow_device below runs it once, or twice: LapGuard).
 int flow_pass(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, int H, int W, int C, int levels,
               const papof_params& P, double* d_vx, double* d_vy, double* d_warp, double* timing, LapGuard* lg) {
+    const double t_entry = wall();
     PAPOF_TRY(check_params(P, levels));
     double ratio = P.ratio;
     if (ratio > 0.98 || ratio < 0.4) ratio = 0.75;
@@ -1174,7 +1175,10 @@ int flow_pass(papof_handle* h, const FrameIn& fa, const FrameIn& fb, SeqOp op, i
             PAPOF_HIP(hipMemcpyAsync(h->lap_flags_host + first, h->lap_flags_dev + first, bytes, hipMemcpyDeviceToHost, h->stream));
         h->stamps_fetched = h->stamps_used;
     }
+    const double t_enqueued = wall();
     PAPOF_HIP(hipStreamSynchronize(h->stream));
+    h->host_enqueue_sec = t_enqueued - t_entry;
+    h->host_wait_sec = wall() - t_enqueued;
     h->next_stamp = nullptr;
     if (P.sor_mode == PAPOF_SOR_EXACT) PAPOF_TRY(sor_check(h));
     if (clk.err != PAPOF_OK || pclk.err != PAPOF_OK || total.err != PAPOF_OK) return PAPOF_EDEVICE;
@@ -2313,6 +2317,14 @@ int papof_lap_guard_stats(papof_handle* h, int out[4]) {
     out[1] = h->lap_exact_calls;
     out[2] = h->lap_exact ? 1 : 0;
     out[3] = h->lap_guard ? 1 : 0;
+    return PAPOF_OK;
+}
+
+int papof_last_host_times(papof_handle* h, double out[3]) {
+    if (!h || !out) return PAPOF_EINVAL;
+    out[0] = h->host_enqueue_sec;
+    out[1] = h->host_wait_sec;
+    out[2] = 0.0;
     return PAPOF_OK;
 }
 

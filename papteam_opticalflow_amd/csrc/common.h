@@ -40,6 +40,20 @@ struct Rect {
     __host__ __device__ int h() const { return y1 - y0; }
 };
 
+// BATCHED launches (api.hip: flow_batch -- B frame pairs of one shape per launch chain, the reference's TestSuite walking a
+// collection of small frames, Code/Serial/TestSuite.py:69-81): every buffer of the call is an ARRAY over the pairs (or over the
+// frames) of the batch, and a kernel's blockIdx.y (the layout converters: blockIdx.z) is the item it works on -- each of its
+// pointers advanced by that item's stride, in elements of the pointee.  All zero = the ordinary single call.
+struct BatchK {
+    size_t im;    // per-frame planes (pyramid levels, features, smoothed features, derivative planes) between one pair's frame
+                  // and the next pair's: frame stride x 1 (a sequence: pair p = frames p, p + 1) or x 2 (independent pairs)
+    size_t uv;    // the flow planes of a pair
+    size_t sp;    // the solver's coefficient planes
+    size_t d;     // ... and its (du, dv) planes
+    size_t wit;   // witness words of the Laplacian-noise guard (unsigned)
+    size_t out;   // the interleaved result image
+};
+
 struct Taps {                  // 1-D correlation taps, passed by value as a kernel argument
     double t[2 * kMaxFsize + 1];
     int fsize;
@@ -299,6 +313,7 @@ struct papof_handle {
     bool lap_exact = false;    // the next call starts in the exact pass (its predecessor ended with a channel lacking a proof)
     unsigned lap_epoch = 0;    // a flag is SET when it holds the number of the pass that wrote it: nothing is ever cleared
     int lap_reruns = 0, lap_exact_calls = 0;  // statistics (papof_lap_guard_stats)
+    double host_enqueue_sec = 0.0, host_wait_sec = 0.0;  // host wall time of the last call: enqueueing / waiting (papof_last_host_times)
     // Host buffers handed to the call itself (flow_host -> flow_device): the call then issues the PCIe copies where they
     // overlap device work -- frame 2 uploads while frame 1's share of the preparation runs, (vx, vy) go back beside the
     // final bicubic warp, warpI2 in row chunks behind its kernel's chunks -- on a stream of their own.
@@ -345,8 +360,8 @@ inline unsigned long long* take_stamp(papof_handle* h) {
 int stamp_only(papof_handle* h);  // kernels.hip
 
 // ---- kernels.hip: launch wrappers (all asynchronous on h->stream) ----
-int hwc_to_planar(papof_handle* h, const double* hwc, double* planar, int H, int W, int C);
-int hwc_u8_to_planar(papof_handle* h, const unsigned char* hwc, double* planar, int H, int W, int C);
+int hwc_to_planar(papof_handle* h, const double* hwc, double* planar, int H, int W, int C, int frames = 1);
+int hwc_u8_to_planar(papof_handle* h, const unsigned char* hwc, double* planar, int H, int W, int C, int frames = 1);
 int planar_to_hwc(papof_handle* h, const double* planar, double* hwc, int H, int W, int C);
 int filter_h(papof_handle* h, const double* src, double* dst, int H, int W, int planes, const Taps& f,
              const Rect* rc = nullptr);
@@ -356,7 +371,8 @@ int filter_hv(papof_handle* h, const double* src, double* dst, double* tmp, int 
               const Taps& fv);  // both passes in one launch (same bits); `tmp` only for half-widths beyond the fused kernel's
 int resize(papof_handle* h, const double* src, double* dst, int sh, int sw, int planes, int dh, int dw, double xr,
            double yr, bool use_post, double post, const Rect* rc = nullptr);
-int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C, unsigned* nz = nullptr);
+int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C, unsigned* nz = nullptr, int frames = 1,
+               size_t nz_stride = 0);  // frames > 1: contiguous frames of a batch (common.h: BatchK)
 int central3_planes(papof_handle* h, const double* src, double* gx, double* gy, double* gxy, int H, int W, int planes);
 int warp_bilinear(papof_handle* h, const double* im1, const double* im2, const double* vx, const double* vy,
                   double* out, int H, int W, int planes, const Rect* rc = nullptr);
@@ -375,7 +391,8 @@ int assemble_system(papof_handle* h, const double* blend, const double* imdt, co
                     const double* gm = nullptr, const double* lap = nullptr);
 int flow_system(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, const double* im1s,
                 int H, int W, int planes, double alpha, double omega, const SorPlanes& out, unsigned* wit = nullptr,
-                int row0 = 0, int row1 = -1);  // rows row0 .. row1-1 (a rank's range of rows: tiles.hip)
+                int row0 = 0, int row1 = -1,  // rows row0 .. row1-1 (a rank's range of rows: tiles.hip)
+                int batch = 1, const BatchK* bk = nullptr);  // pairs of a batch (blockIdx.y), each pointer advanced by its stride
 int lap_scratch_doubles();
 int lap_rows_check(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H, int W,
                    int C, int r0, int r1, unsigned* wit, unsigned* val, unsigned mark);  // rows r0 .. r1-1, every pixel
@@ -392,13 +409,14 @@ int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, 
                     const double* im2, double* warp, int H, int W, int planes, bool do_warp = true);
 int bicubic_warp(papof_handle* h, const double* im1, const double* im2, const double* gx, const double* gy,
                  const double* gxy, const double* vx, const double* vy, double* out_hwc, int H, int W, int C,
-                 const Rect* rc = nullptr, bool planar_out = false, bool clamp = true);
+                 const Rect* rc = nullptr, bool planar_out = false, bool clamp = true, int batch = 1, const BatchK* bk = nullptr);
 int flow_quantize16(papof_handle* h, const double* vx, const double* vy, unsigned short* q, size_t n);
 int flow_dequantize16(papof_handle* h, const unsigned short* q, double* vx, double* vy, size_t n);
 int flow_to_bgr(papof_handle* h, const double* vx, const double* vy, size_t n, double* partial, unsigned char* bgr);
 int update_warp_phi(papof_handle* h, const SorPlanes& sp, const double* u, const double* v, double* u_out, double* v_out,
                     const double* im1, const double* im2, double* warp, double* phi_out, int H, int W, int planes,
-                    bool do_warp = true, int row0 = 0, int row1 = -1, unsigned* wit = nullptr);
+                    bool do_warp = true, int row0 = 0, int row1 = -1, unsigned* wit = nullptr, int batch = 1,
+                    const BatchK* bk = nullptr);
 int update_flow(papof_handle* h, const SorPlanes& sp, double* u, double* v, int H, int W, const Rect& r);
 int sor_prep(papof_handle* h, const double* phi, const double* imdxy, const double* imdx2, const double* imdy2,
              const double* rhs1, const double* rhs2, int H, int W, double alpha, double omega, const SorPlanes& out);
@@ -409,7 +427,15 @@ Taps deriv5_taps();
 Taps central3_taps();
 
 // ---- sor.hip ----
-int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor, int mode);
+// bt: B solves of one shape in one launch (api.hip: flow_batch) -- the operands of pair p are sp's advanced by these strides
+// (doubles; counters: unsigneds; `tiny`: the row-major planes of k_sor_tiny's levels); exact order only, the plain one-sweep-per-wave
+// kernel or k_sor_tiny, counters cleared ahead by the caller (papof_handle::sor_prog_next)
+struct SorBatch {
+    int n;
+    size_t coef, d, prog, tiny;
+};
+int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor, int mode,
+              const SorBatch* bt = nullptr);
 int sor_redblack_halfsweep(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int colour,
                            const Rect& r);
 int sor_blocked_depth(const papof_handle* h, int mode, int H, int W);  // half-sweeps per launch the blocked solver uses
@@ -441,6 +467,7 @@ int sor_alloc_planes(Arena& A, int H, int W, int mode, int n_sor_cap, SorPlanes&
 int sor_bind(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor);  // choose the layout of the next solves (skew mode)
 int sor_group_size(const papof_handle* h, int H, int W, int n_sor);   // sweeps per workgroup the solver will use
 int sor_reset_planes(papof_handle* h, const SorPlanes& sp);    // zero all padding of the bound layout
+int sor_reset_planes_batch(papof_handle* h, const SorPlanes& sp, int batch, size_t stride);  // ... of every pair of a batch
 int sor_probe_dpp(papof_handle* h);  // sets h->use_dpp after checking the cross-lane DPP semantics on the device
 
 }  // namespace papof

@@ -127,7 +127,12 @@ int check_params(const papof_params& P, int levels);
 int pyramid_plan(int H, int W, double ratio, int nlev, std::vector<Level>& L, std::vector<PyrPlan>& plan);
 int build_pyramid(papof_handle* h, const std::vector<Level>& L, const std::vector<PyrPlan>& plan, int C, bool second,
                   double* tmp_a, double* tmp_b);
+int smooth_and_resize(papof_handle* h, const double* src, double* dst, double* tmp_a, double* tmp_b, const PyrPlan& p, int C,
+                      int dh, int dw);  // one pyramid level from its source level; C may count the planes of SEVERAL contiguous frames
 int feature_channels(int C);
+// batch.hip: B frame pairs of one shape in one launch chain (host frames in, host results out); falls back to single calls
+int flow_batch_host(papof_handle* h, int n_pairs, int sequence, const void* const* frames, bool u8, int H, int W, int C, int levels,
+                    const papof_params* params, double* const* vx, double* const* vy, double* const* warpI2, double* timing_sec);
 void ensure_strip_streams(papof_handle* h);
 
 }  // namespace papof

@@ -53,6 +53,8 @@ __global__ void k_hwc_to_planar(const double* __restrict__ hwc, double* __restri
     const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
     if (j >= W || i >= H) return;
     const size_t o = (size_t)i * W + j, np = (size_t)H * W;
+    hwc += blockIdx.z * np * C;  // blockIdx.z: the frame of a batch (frames are contiguous on both sides)
+    planar += blockIdx.z * np * C;
     for (int k = 0; k < C; k++) planar[k * np + o] = hwc[o * C + k];
 }
 
@@ -63,6 +65,8 @@ __global__ void k_hwc_u8_to_planar(const unsigned char* __restrict__ hwc, double
     const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;
     if (j >= W || i >= H) return;
     const size_t o = (size_t)i * W + j, np = (size_t)H * W;
+    hwc += blockIdx.z * np * C;  // blockIdx.z: the frame of a batch
+    planar += blockIdx.z * np * C;
     for (int k = 0; k < C; k++) planar[k * np + o] = (double)hwc[o * C + k] / 255.0;
 }
 
@@ -273,7 +277,8 @@ __global__ void k_im2feature(const double* __restrict__ im, double* __restrict__
 constexpr int kFeatRows = PAPOF_V_FEATROWS;
 template <int C>
 __global__ __launch_bounds__(256) void k_im2feature_tiled(const double* __restrict__ im, double* __restrict__ feat, int H,
-                                                          int W, Taps d, unsigned* __restrict__ nz, unsigned mark) {
+                                                          int W, Taps d, unsigned* __restrict__ nz, unsigned mark,
+                                                          size_t b_im, size_t b_feat, size_t b_nz) {
     // nz (may be null): nz[k] is set when feature channel k has a non-zero value anywhere -- a channel that is all zero in BOTH
     // frames has no valid sample for estLaplacianNoise (every |Im1 - warpIm2| is exactly 0), so its LapPara is 0.001 whatever
     // the flow (api.hip: LapGuard).  One ballot per wave, at most one store per wave and channel.
@@ -282,6 +287,9 @@ __global__ __launch_bounds__(256) void k_im2feature_tiled(const double* __restri
     if (!xcd_tile((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows, tx, ty)) return;  // whole workgroup, before any barrier
     const int j0 = tx * BX, i0 = ty * kFeatRows;
     const size_t np = (size_t)H * W;
+    im += blockIdx.y * b_im;  // blockIdx.y: the frame of a batch (common.h: BatchK)
+    feat += blockIdx.y * b_feat;
+    if (nz != nullptr) nz += blockIdx.y * b_nz;
     for (int c = threadIdx.y * BX + threadIdx.x; c < (kFeatRows + 4) * (BX + 4); c += BX * BY) {
         const int r = c / (BX + 4), cc = c - r * (BX + 4);
         g[r][cc] = gray_at<C>(im, np, (size_t)clampi(i0 + r - 2, H) * W + clampi(j0 + cc - 2, W));
@@ -999,7 +1007,18 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
                                                      const double* __restrict__ im1s, int H, int W, double alpha,
                                                      double omega, SkewIdx sk, SixPlanes out, Taps g, Taps d,
                                                      unsigned long long* stamp, unsigned* __restrict__ wit, double wit_thr,
-                                                     unsigned mark, int row0, int row1) {
+                                                     unsigned mark, int row0, int row1, BatchK bk) {
+    {   // blockIdx.y: the pair of a batch (common.h: BatchK)
+        const size_t p = blockIdx.y;
+        im1 += p * bk.im;
+        im2 += p * bk.im;
+        im1s += p * bk.im;
+        u += p * bk.uv;
+        v += p * bk.uv;
+        if (wit != nullptr) wit += p * bk.wit;
+#pragma unroll
+        for (int q = 0; q < 6; q++) out.q[q] += p * bk.sp;
+    }
     // rows row0 .. row1-1 are assembled (a rank's range of rows, tiles.hip: bands_flow; the whole plane otherwise): (u, v) are
     // read on rows row0 - 4 .. row1 + 3 only, the smoothed frame 1 on row0 - 2 .. row1 + 1
     __shared__ double raw[kFW][kFW + 1];            // warped frame 2, pixels (ib - 4 .. ib + 19) x (j0 - 4 .. j0 + 19)
@@ -1356,8 +1375,20 @@ __global__ void k_update_warp_phi(const double* __restrict__ sdu, const double* 
                                   const double* __restrict__ im1, const double* __restrict__ im2,
                                   double* __restrict__ warp, double* __restrict__ phi_out, int H, int W, int planes,
                                   int do_warp, unsigned long long* stamp, int row0, int row1, unsigned* __restrict__ wit,
-                                  double wit_thr, unsigned mark) {
+                                  double wit_thr, unsigned mark, BatchK bk) {
     stamp_now(stamp);
+    {   // blockIdx.y: the pair of a batch (common.h: BatchK; warp and phi_out are not used there)
+        const size_t p = blockIdx.y;
+        sdu += p * bk.d;
+        sdv += p * bk.d;
+        u += p * bk.uv;
+        v += p * bk.uv;
+        u_out += p * bk.uv;
+        v_out += p * bk.uv;
+        im1 += p * bk.im;
+        im2 += p * bk.im;
+        if (wit != nullptr) wit += p * bk.wit;
+    }
     int tbx, tby;  // a contiguous run of blocks per XCD (xcd_tile): blocks above each other share the lines of the banded (du, dv)
     if (!xcd_tile((W + BX - 1) / BX, (row1 - row0 + BY - 1) / BY, tbx, tby)) return;
     const int j = tbx * BX + threadIdx.x, i = row0 + tby * BY + threadIdx.y;  // rows row0 .. row1-1
@@ -1456,7 +1487,18 @@ __global__ void k_bicubic(const double* __restrict__ im1, const double* __restri
                           const double* __restrict__ gx, const double* __restrict__ gy,
                           const double* __restrict__ gxy, const double* __restrict__ vx,
                           const double* __restrict__ vy, double* __restrict__ out, int H, int W, int C, Rect rc,
-                          unsigned long long* stamp, int planar_out, int clamp) {
+                          unsigned long long* stamp, int planar_out, int clamp, BatchK bk) {
+    {   // blockIdx.y: the pair of a batch (common.h: BatchK)
+        const size_t p = blockIdx.y;
+        im1 += p * bk.im;
+        im2 += p * bk.im;
+        gx += p * bk.im;
+        gy += p * bk.im;
+        gxy += p * bk.im;
+        vx += p * bk.uv;
+        vy += p * bk.uv;
+        out += p * bk.out;
+    }
     // planar_out / clamp: the in-loop use on the feature planes (src/OpticalFlow.cpp:517-521 with threshold(), :816
     // without); the final warp of the originals writes interleaved HWC and always clamps.
     stamp_now(stamp);
@@ -1661,14 +1703,14 @@ Taps central3_taps() {  // src/Image.h:2589
 
 #define LAUNCH_CHECK() PAPOF_HIP(hipGetLastError())
 
-int hwc_to_planar(papof_handle* h, const double* hwc, double* planar, int H, int W, int C) {
-    hipLaunchKernelGGL(k_hwc_to_planar, grid2d(W, H), dim3(BX, BY), 0, h->stream, hwc, planar, H, W, C);
+int hwc_to_planar(papof_handle* h, const double* hwc, double* planar, int H, int W, int C, int frames) {
+    hipLaunchKernelGGL(k_hwc_to_planar, grid2d(W, H, frames), dim3(BX, BY), 0, h->stream, hwc, planar, H, W, C);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
 
-int hwc_u8_to_planar(papof_handle* h, const unsigned char* hwc, double* planar, int H, int W, int C) {
-    hipLaunchKernelGGL(k_hwc_u8_to_planar, grid2d(W, H), dim3(BX, BY), 0, h->stream, hwc, planar, H, W, C);
+int hwc_u8_to_planar(papof_handle* h, const unsigned char* hwc, double* planar, int H, int W, int C, int frames) {
+    hipLaunchKernelGGL(k_hwc_u8_to_planar, grid2d(W, H, frames), dim3(BX, BY), 0, h->stream, hwc, planar, H, W, C);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
@@ -1745,14 +1787,17 @@ int resize(papof_handle* h, const double* src, double* dst, int sh, int sw, int 
     return PAPOF_OK;
 }
 
-int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C, unsigned* nz) {
+int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, int C, unsigned* nz, int frames, size_t nz_stride) {
+    // frames > 1 (a batch): frame f reads im + f * (C planes), writes feat + f * (5 or 3 planes), flags nz + f * nz_stride
+    const size_t np = (size_t)H * W;
     if (C == 3) {
-        hipLaunchKernelGGL(k_im2feature_tiled<3>, dim3(xcd_grid((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows)), dim3(BX, BY), 0,
-                           h->stream, im, feat, H, W, deriv5_taps(), nz, h->lap_epoch);
+        hipLaunchKernelGGL(k_im2feature_tiled<3>, dim3(xcd_grid((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows), frames), dim3(BX, BY), 0,
+                           h->stream, im, feat, H, W, deriv5_taps(), nz, h->lap_epoch, 3 * np, 5 * np, nz_stride);
     } else if (C == 1) {
-        hipLaunchKernelGGL(k_im2feature_tiled<1>, dim3(xcd_grid((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows)), dim3(BX, BY), 0,
-                           h->stream, im, feat, H, W, deriv5_taps(), nz, h->lap_epoch);
+        hipLaunchKernelGGL(k_im2feature_tiled<1>, dim3(xcd_grid((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows), frames), dim3(BX, BY), 0,
+                           h->stream, im, feat, H, W, deriv5_taps(), nz, h->lap_epoch, np, 3 * np, nz_stride);
     } else {  // src/OpticalFlow.cpp:956-957: any other channel count is passed through
+        if (frames != 1) return PAPOF_EINVAL;
         PAPOF_HIP(hipMemcpyAsync(feat, im, sizeof(double) * (size_t)H * W * C, hipMemcpyDeviceToDevice, h->stream));
         return PAPOF_OK;
     }
@@ -1858,19 +1903,21 @@ int assemble_system(papof_handle* h, const double* blend, const double* imdt, co
 // k_flow_system: the default branches of warp_smooth_blend() + assemble_system() in one launch (exact-order layout, 5 or 3
 // feature channels); returns PAPOF_EINVAL where it does not apply
 int flow_system(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, const double* im1s,
-                int H, int W, int planes, double alpha, double omega, const SorPlanes& out, unsigned* wit, int row0, int row1) {
+                int H, int W, int planes, double alpha, double omega, const SorPlanes& out, unsigned* wit, int row0, int row1,
+                int batch, const BatchK* bk) {
     if (planes != 5 && planes != 3) return PAPOF_EINVAL;
     if (row1 < 0) row1 = H;
     if (row0 < 0 || row1 > H) return PAPOF_EINVAL;
     if (row1 <= row0) return PAPOF_OK;
     const int ntiles = ((W + kFT - 1) / kFT) * ((row1 - row0 + kFT - 1) / kFT);
-    const dim3 grid(8 * ((ntiles + 7) / 8));  // (the kernel maps block -> tile: a contiguous run of tiles per XCD)
+    const dim3 grid(8 * ((ntiles + 7) / 8), batch);  // (the kernel maps block -> tile: a contiguous run of tiles per XCD)
     const SixPlanes six{{out.phi, out.xy, out.a1, out.a2, out.b1, out.b2}};
+    const BatchK bk0{0, 0, 0, 0, 0, 0};
     const auto kern = out.skew ? (planes == 5 ? k_flow_system<5, true> : k_flow_system<3, true>)
                                : (planes == 5 ? k_flow_system<5, false> : k_flow_system<3, false>);
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, h->stream, im1, im2, u, v, im1s, H, W, alpha, omega,
                        out.skew ? skew_idx(out) : SkewIdx{0, 0, 0, 0, 0, 0, 0, 0, 0}, six, smooth5_taps(), deriv5_taps(),
-                       take_stamp(h), wit, 2e-20 * (double)H * (double)W, h->lap_epoch, row0, row1);
+                       take_stamp(h), wit, 2e-20 * (double)H * (double)W, h->lap_epoch, row0, row1, bk ? *bk : bk0);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
@@ -1896,21 +1943,23 @@ int update_and_warp(papof_handle* h, const SorPlanes& sp, double* u, double* v, 
 
 int update_warp_phi(papof_handle* h, const SorPlanes& sp, const double* u, const double* v, double* u_out, double* v_out,
                     const double* im1, const double* im2, double* warp, double* phi_out, int H, int W, int planes,
-                    bool do_warp, int row0, int row1, unsigned* wit) {
+                    bool do_warp, int row0, int row1, unsigned* wit, int batch, const BatchK* bk) {
     const double wit_thr = 2e-20 * (double)H * (double)W;
+    const BatchK bk0{0, 0, 0, 0, 0, 0};
+    if (batch > 1 && (warp || phi_out || do_warp)) return PAPOF_EINVAL;
     if (u == u_out || v == v_out) return PAPOF_EINVAL;
     if (row1 < 0) row1 = H;
     if (row0 < 0 || row1 > H) return PAPOF_EINVAL;
     if (row1 <= row0) return PAPOF_OK;
-    const dim3 grid(xcd_grid((W + BX - 1) / BX, (row1 - row0 + BY - 1) / BY));
+    const dim3 grid(xcd_grid((W + BX - 1) / BX, (row1 - row0 + BY - 1) / BY), batch);
     if (sp.skew)
         hipLaunchKernelGGL(k_update_warp_phi<true>, grid, dim3(BX, BY), 0, h->stream, sp.du, sp.dv, skew_idx(sp),
                            u, v, u_out, v_out, im1, im2, warp, phi_out, H, W, planes, do_warp ? 1 : 0, take_stamp(h),
-                           row0, row1, wit, wit_thr, h->lap_epoch);
+                           row0, row1, wit, wit_thr, h->lap_epoch, bk ? *bk : bk0);
     else
         hipLaunchKernelGGL(k_update_warp_phi<false>, grid, dim3(BX, BY), 0, h->stream, sp.du, sp.dv,
                            SkewIdx{0, 0, 0, 0, 0, 0, 0, 0, 0}, u, v, u_out, v_out, im1, im2, warp, phi_out, H, W, planes,
-                           do_warp ? 1 : 0, take_stamp(h), row0, row1, wit, wit_thr, h->lap_epoch);
+                           do_warp ? 1 : 0, take_stamp(h), row0, row1, wit, wit_thr, h->lap_epoch, bk ? *bk : bk0);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }
@@ -1952,11 +2001,12 @@ int flow_to_bgr(papof_handle* h, const double* vx, const double* vy, size_t n, d
 
 int bicubic_warp(papof_handle* h, const double* im1, const double* im2, const double* gx, const double* gy,
                  const double* gxy, const double* vx, const double* vy, double* out_hwc, int H, int W, int C,
-                 const Rect* rc, bool planar_out, bool clamp) {
+                 const Rect* rc, bool planar_out, bool clamp, int batch, const BatchK* bk) {
     const Rect r = region(rc, W, H);
     if (r.empty()) return PAPOF_OK;
-    hipLaunchKernelGGL(k_bicubic, dim3(xcd_grid((r.x1 - r.x0 + BX - 1) / BX, (r.y1 - r.y0 + BY - 1) / BY)), dim3(BX, BY), 0, h->stream, im1, im2, gx, gy, gxy, vx, vy, out_hwc, H, W,
-                       C, r, take_stamp(h), planar_out ? 1 : 0, clamp ? 1 : 0);
+    const BatchK bk0{0, 0, 0, 0, 0, 0};
+    hipLaunchKernelGGL(k_bicubic, dim3(xcd_grid((r.x1 - r.x0 + BX - 1) / BX, (r.y1 - r.y0 + BY - 1) / BY), batch), dim3(BX, BY), 0, h->stream, im1, im2, gx, gy, gxy, vx, vy, out_hwc, H, W,
+                       C, r, take_stamp(h), planar_out ? 1 : 0, clamp ? 1 : 0, bk ? *bk : bk0);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }

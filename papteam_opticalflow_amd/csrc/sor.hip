@@ -125,6 +125,9 @@ struct ExactArgs {
     unsigned* peer_prog;  // its progress counters of this solve
     int top_cut;          // band b0 has its upper neighbour on another rank: read the inbox cell
     int bot_cut;          // band b0 + nbl - 1 has its lower neighbour on another rank: also write that rank's inbox / counter
+    // BATCHED solves (api.hip: flow_batch): blockIdx.y is the frame pair; its operands are the first pair's advanced by these
+    // strides -- doubles between the pairs' coefficient planes / (du, dv) planes, unsigneds between their counters.  0: one solve.
+    size_t bs_coef, bs_d, bs_prog;
 };
 
 __device__ __forceinline__ void stamp_now(unsigned long long* s) {
@@ -455,8 +458,17 @@ __device__ __forceinline__ bool wait_covered(const ExactArgs& A, const Polls& pl
 }
 
 template <int R, bool DPP, bool SPLIT = false>
-__global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A) {
+__global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A_in) {
     static_assert(R >= 4 && R % 2 == 0, "two markers per iteration");
+    ExactArgs A = A_in;
+    {   // the frame pair of a batched launch (wave-uniform: scalar arithmetic on the kernel arguments)
+        const size_t p = blockIdx.y;
+        A.phi += p * A.bs_coef;
+        A.a1 += p * A.bs_coef;
+        A.b1 += p * A.bs_coef;
+        A.du += p * A.bs_d;
+        A.prog += p * A.bs_prog;
+    }
     stamp_now(A.stamp);
     const unsigned lane = threadIdx.x;
     // Workgroups are dealt round-robin over the 8 XCDs (blocks x and x + 8 share one; observed, speed only), so with
@@ -1661,10 +1673,23 @@ struct TinyArgs {
     int H, W, K;
     int Q, QP;  // segments per row, lanes per row = ceil(Q / 2)
     double nalpha, om1;
+    size_t bstride;  // batched solves: doubles between the planes of consecutive frame pairs (blockIdx.x = the pair); else 0
 };
 
 template <int C, int NW>  // NW: the most waves a launch may have (register budget); a launch has as many as its lanes need
-__global__ __launch_bounds__(NW * 64) void k_sor_tiny(TinyArgs A) {
+__global__ __launch_bounds__(NW * 64) void k_sor_tiny(TinyArgs A_in) {
+    TinyArgs A = A_in;
+    {
+        const size_t o = (size_t)blockIdx.x * A.bstride;
+        A.phi += o;
+        A.xy += o;
+        A.a1 += o;
+        A.a2 += o;
+        A.b1 += o;
+        A.b2 += o;
+        A.du += o;
+        A.dv += o;
+    }
     // LDS layout: cell (row r, column j) -> ((r + 1) * 2C + j % 2C) * (QP + 2) + j / 2C + 1: within a row the cells that the
     // lanes of a row address with the SAME register index (same position in a lane's pair of tiles) are contiguous, so a
     // wave's 16-byte accesses fall on consecutive cells -- no bank conflicts for any C (row-major cells would be 2C cells
@@ -1942,7 +1967,8 @@ bool sor_tiny_fits(const papof_handle* h, int H, int W, int n_sor) {
     return !off && H >= 1 && W >= 1 && n_sor >= 1 && tiny_shape(H, W, n_sor, t);
 }
 
-static int sor_tiny_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor) {
+static int sor_tiny_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor,
+                          int batch = 1, size_t bstride = 0) {
     TinyShape t;
     if (sp.skew || !tiny_shape(H, W, n_sor, t)) return PAPOF_EINVAL;
     TinyArgs A;
@@ -1961,6 +1987,7 @@ static int sor_tiny_solve(papof_handle* h, const SorPlanes& sp, int H, int W, do
     A.QP = (A.Q + 1) / 2;
     A.nalpha = -alpha;
     A.om1 = 1 - omega;
+    A.bstride = batch > 1 ? bstride : 0;
     const size_t lds = (size_t)(H + 2) * 2 * t.c * (A.QP + 2) * 16;
 #define PAPOF_TINY(CC, NWW)                                                                                           \
     do {                                                                                                              \
@@ -1970,7 +1997,7 @@ static int sor_tiny_solve(papof_handle* h, const SorPlanes& sp, int H, int W, do
                                           150 * 1024));                                                               \
             attr_set = true;                                                                                          \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_sor_tiny<CC, NWW>), dim3(1), dim3(t.waves * 64), lds, h->stream, A);                    \
+        hipLaunchKernelGGL((k_sor_tiny<CC, NWW>), dim3(batch), dim3(t.waves * 64), lds, h->stream, A);                    \
     } while (0)
     if (t.c == 1)
         PAPOF_TINY(1, 16);
@@ -2066,9 +2093,12 @@ int sor_plan(const papof_handle* h, int H, int W, int n_sor, int mode, int* laun
     return PAPOF_OK;
 }
 
-int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor, int mode) {
+int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor, int mode,
+              const SorBatch* bt) {
     const double nalpha = -alpha, om1 = 1 - omega;
     if (n_sor <= 0) return PAPOF_EINVAL;
+    const int batch = bt ? bt->n : 1;
+    if (batch < 1 || (bt && mode != PAPOF_SOR_EXACT)) return PAPOF_EINVAL;
     const auto mark = [&](int on) {
         if (h->sor_mark) h->sor_mark(h->sor_mark_ctx, on);
     };
@@ -2078,7 +2108,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
     };
     if (mode == PAPOF_SOR_EXACT && !sp.skew) {  // row-major operands: the plane is solved inside one workgroup (k_sor_tiny)
         mark(1);
-        PAPOF_TRY(sor_tiny_solve(h, sp, H, W, alpha, omega, n_sor));
+        PAPOF_TRY(sor_tiny_solve(h, sp, H, W, alpha, omega, n_sor, batch, bt ? bt->tiny : 0));
         mark(0);
         log_solve(6, 0, 1);
         return PAPOF_OK;
@@ -2090,8 +2120,9 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
             return PAPOF_EINVAL;  // sor_bind() must have chosen this layout (the operands were assembled in it)
         if ((sd.n + kLanes) * 16 >= (size_t(1) << 30) || (sd.nd + sd.nh) * 16 >= (size_t(1) << 30))
             return PAPOF_EINVAL;  // 32-bit byte offsets, see kOob
+        if (bt && (sd.fuse != 1 || sd.group != 1 || !h->sor_prog_next)) return PAPOF_EINVAL;  // batches: the plain kernel, counters cleared ahead
         const size_t words = (size_t)sd.nb * n_sor * kProgStride + kProgStride;
-        if (words > h->sync_cap) {
+        if (!bt && words > h->sync_cap) {
             PAPOF_HIP(hipStreamSynchronize(h->stream));
             if (h->sync_words) PAPOF_HIP(hipFree(h->sync_words));
             h->sync_words = nullptr;
@@ -2141,7 +2172,10 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.peer_du = nullptr;
         A.peer_prog = nullptr;
         A.top_cut = A.bot_cut = 0;
-        A.dbg = h->sor_dbg;
+        A.bs_coef = bt ? bt->coef : 0;
+        A.bs_d = bt ? bt->d : 0;
+        A.bs_prog = bt ? bt->prog : 0;
+        A.dbg = bt ? nullptr : h->sor_dbg;
         // Fault injection for the tests (tests/test_gpu_parity.py): raise the abort word before the launch, as a task whose
         // bounded wait expired would -- every task must then END (s_endpgm on the fast path, the polling loops' abort
         // check elsewhere) and the call must report PAPOF_ETIMEOUT instead of hanging or returning numbers.
@@ -2155,7 +2189,9 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         // (1920x1080: 0.941 -> 0.900 ms, 607x341: 0.354 -> 0.338 ms, a whole 1080p pair 11.98 -> 11.56 ms).
         static const char* const clear_env = std::getenv("PAPOF_SOR_CLEAR");
         static const bool clear_tail_only = clear_env && std::strcmp(clear_env, "tail") == 0;
-        if (sd.group > 1 || !clear_tail_only) {
+        if (bt) {  // every pair's two planes in one fill node (the pairs' planes lie bt->d doubles apart)
+            PAPOF_HIP(hipMemset2DAsync(sp.du, bt->d * sizeof(double), 0, sd.nd * 16, (size_t)batch, h->stream));
+        } else if (sd.group > 1 || !clear_tail_only) {
             PAPOF_HIP(hipMemsetAsync(sp.du, 0, (sd.nd + sd.nh) * 16, h->stream));  // both planes (+ the halo rows)
         } else {
             const size_t block = (size_t)sd.nb * kLanes * 16, par = (size_t)sd.npos_d * block;
@@ -2243,6 +2279,11 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         // measured: with at most one band per XCD the affinity is worth 3-4 % (small pyramid levels); beyond that the
         // uneven band count per XCD costs more than the L2 hits give (1920x1080: 18 bands over 8 XCDs, -5 %)
         A.xcd_affine = (h->sor_xcd_affine && (sd.nb <= 8 || h->sor_xcd_affine > 1)) ? 1 : 0;
+        // Batched launches: NO affinity.  It would put band b of EVERY pair on XCD b % 8 -- the three bands of sixteen 240x135
+        // pairs on XCDs 0..2 -- and pad a sweep's row of tasks to 8 blocks, which cuts a solve into more launches: measured
+        // 1.49 vs 0.61 ms of solver time per pair in a batch of 16 (profiles/r04_batch_knobs.txt; rotating the bands per pair so
+        // that the XCDs are loaded equally: 0.82).
+        if (bt) A.xcd_affine = 0;
         const int per_k = A.xcd_affine ? 8 * ((sd.nb + 7) / 8) : sd.nb;  // workgroups per sweep
         const dim3 block(kLanes);
         // pipeline depth: every load is issued R steps ahead and a task looks 2R steps ahead of its producers, so R is
@@ -2251,12 +2292,12 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         // small, hand-off-bound levels the shorter one (607x341: 0.53 -> 0.47 ms).
         const int R = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 8 ? 8 : 6);  // (in-pair A/B of round 2: 6 / 10 on the big
                                                                                 // levels, 4 / 8 on the small ones: all worse)
-        const int chunk = std::max(1, resident_tasks(h) / per_k);
+        const int chunk = std::max(1, resident_tasks(h) / (per_k * batch));  // (every task of a launch resident: all pairs' count)
         for (int k0 = 0; k0 < n_sor; k0 += chunk) {
             A.k0 = k0;
             h->sor_launches++;
             A.stamp = nullptr;
-            const dim3 grid(per_k * std::min(chunk, n_sor - k0));
+            const dim3 grid(per_k * std::min(chunk, n_sor - k0), batch);
             if (!h->use_dpp)
                 hipLaunchKernelGGL((k_sor_exact<8, false>), grid, block, 0, h->stream, A);
             else if (R <= 4)
@@ -2436,6 +2477,7 @@ int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double a
     A.xcd_affine = 0;
     A.dbg = nullptr;
     A.stamp = nullptr;
+    A.bs_coef = A.bs_d = A.bs_prog = 0;
     A.peer_du = split ? split->peer_du : nullptr;
     A.peer_prog = split ? split->peer_prog : nullptr;
     A.top_cut = split && split->top_cut ? 1 : 0;
@@ -2498,6 +2540,13 @@ int sor_reset_planes(papof_handle* h, const SorPlanes& sp) {
     if (!sp.skew) return PAPOF_OK;
     PAPOF_HIP(hipMemsetAsync(sp.phi, 0, 3 * plane_pitch(sp.sd) * sizeof(double), h->stream));
     return PAPOF_OK;  // the (du, dv) planes are cleared by every solve
+}
+
+// ... of every pair of a batch at once: the pairs' operand blocks lie `stride` doubles apart (api.hip / batch.hip: flow_batch)
+int sor_reset_planes_batch(papof_handle* h, const SorPlanes& sp, int batch, size_t stride) {
+    if (!sp.skew) return PAPOF_OK;
+    PAPOF_HIP(hipMemset2DAsync(sp.phi, stride * sizeof(double), 0, 3 * plane_pitch(sp.sd) * sizeof(double), (size_t)batch, h->stream));
+    return PAPOF_OK;
 }
 
 // Sweeps per workgroup of the exact-order solver for this problem: the grouped kernel needs the verified DPP lane

@@ -15,9 +15,18 @@ video = ([a, b] * (n_pairs // 2 + 1))[:n_pairs + 1]
 h, w, _ = a.shape
 tag = "overlap=%s queues=%s" % (os.environ.get("PAPOF_OVERLAP", "1"), os.environ.get("GPU_MAX_HW_QUEUES", "default"))
 for k in ks:
-    flow_collection(video[:2 * k + 1], 5, in_flight=k, on_pair=lambda *r: None)  # handles, arenas, warm-up
+    flow_collection(video[:2 * k + 1], 5, in_flight=k, batch=0, on_pair=lambda *r: None)  # handles, arenas, warm-up
     t0 = time.perf_counter()
-    flow_collection(video, 5, in_flight=k, on_pair=lambda *r: None)
+    flow_collection(video, 5, in_flight=k, batch=0, on_pair=lambda *r: None)
     dt = time.perf_counter() - t0
     print("%sx%s  %3d pairs  %s  in flight %2d : %7.2f ms per pair  %7.2f Mpix/s  %6.1f pairs/s"
           % (w, h, n_pairs, tag, k, dt / n_pairs * 1e3, n_pairs * h * w / 1e6 / dt, n_pairs / dt), flush=True)
+# the same collection in batches (csrc/batch.hip): B pairs per launch chain, 1 / 2 chains in flight
+for B in [int(x) for x in os.environ.get("PROBE_BATCHES", "8,16,32").split(",")]:
+    for k in (1, 2):
+        flow_collection(video, 5, in_flight=k, batch=B, on_pair=lambda *r: None)
+        t0 = time.perf_counter()
+        flow_collection(video, 5, in_flight=k, batch=B, on_pair=lambda *r: None)
+        dt = time.perf_counter() - t0
+        print("%sx%s  %3d pairs  batches of %2d, %d chains in flight : %7.2f ms per pair  %7.2f Mpix/s  %6.1f pairs/s"
+              % (w, h, n_pairs, B, k, dt / n_pairs * 1e3, n_pairs * h * w / 1e6 / dt, n_pairs / dt), flush=True)
