@@ -121,9 +121,12 @@ _collection_handles = {}  # device -> handles kept between flow_collection calls
 
 
 def collection_in_flight(height, width):
-    """Sequences flow_collection() keeps in flight by default: small frames leave the chip idle and their calls are bound by
-    the host's launch path, so many run side by side (measured on MI355X, reference schedule, tools/collection_probe.py:
-    240x135 and 480x270 peak at 16, 960x540 is flat from 4 to 16, 1920x1080 peaks at 4)."""
+    """Sequences the UNBATCHED flow_collection() keeps in flight by default: small frames leave the chip idle, so many calls run
+    side by side (measured on MI355X, reference schedule, tools/collection_probe.py: 240x135 and 480x270 peak at 16, 960x540 is
+    flat from 4 to 16, 1920x1080 peaks at 4).  What caps that at ~2 ms per 240x135 pair is NOT the host's launch path -- a call
+    spends 1.0 of its 24 ms enqueueing, with 16 threads as with one -- but the device's dispatch of ~84 k small dependent kernels
+    per second over 16 queues, each stretched to 50-65 us (tools/collection_trace.py, tools/trace_concurrency.py;
+    profiles/r04_collection_trace_240.txt, r04_collection_concurrency_240x16.txt): hence the batched path, collection_batch()."""
     mpix = height * width / 1e6
     return 16 if mpix <= 0.3 else (8 if mpix <= 1.0 else 4)
 

@@ -18,9 +18,9 @@
 // video) builds every frame's pyramid and features once.
 //
 // The Laplacian-noise guard (api.hip: LapGuard; src/OpticalFlow.cpp:399-400): the batch runs the OPTIMISTIC pass with one block
-// of witness flags per pair and non-zero flags per frame; a pair that ends without a proof for a consulted estimate (duplicate
-// frames; the few-pixel levels of a 15-level pyramid, whose exhaustive one-block check the batch does not have) is run again
-// through the single call, which has the exact pass.  Results: the reference's, either way.
+// of witness flags per pair and non-zero flags per frame (few-pixel levels: an exhaustive check behind every update); a pair that
+// ends without a proof for a consulted estimate (duplicate frames) is run again through the single call, which has the exact
+// pass.  Results: the reference's, either way.
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -208,18 +208,24 @@ int flow_batch_device(papof_handle* h, int B, int sequence, const void* const* f
             bk.wit = kLapFlagWords;
             const SorBatch bt{B, sp_stride, spd_stride, LC[k].per, st_stride};
             const double *f1 = F[k], *f2 = F[k] + np * fc, *s1 = S[k];
+            // Few-pixel levels (the deep end of an 8- or 15-level pyramid): the flow leaves the image altogether in some iterations,
+            // every warped value is then frame 1's and there is NO valid sample -- which only a look at every pixel can tell from
+            // "no witness among the samples".  There the estimate behind EVERY update is checked exhaustively (one small block per
+            // pair and channel): a witness, or the constant 0.001 (kLapNone).
+            const bool exhaustive = guard && np <= 4096;
             for (int count = 0; count < n_outer; count++) {
-                unsigned* const w_prev = guard && count > 0 ? wit + lap_wit_word(slot - 1) : nullptr;
+                unsigned* const w_prev = guard && !exhaustive && count > 0 ? wit + lap_wit_word(slot - 1) : nullptr;
                 PAPOF_TRY(flow_system(h, f1, f2, uv, uv + np, s1, lh, lw, fc, P.alpha, P.omega, sp, w_prev, 0, -1, B, &bk));
                 h->sor_prog_next = tiny ? nullptr : h->sync_words + 32 + LC[k].off + (size_t)count * LC[k].per * B;
                 const int rc = sor_solve(h, sp, lh, lw, P.alpha, P.omega, K, PAPOF_SOR_EXACT, &bt);
                 h->sor_prog_next = nullptr;
                 PAPOF_TRY(rc);
                 // the estimate behind the level's last update is witnessed by the update kernel itself (nobody evaluates that warp)
-                unsigned* const w_now = guard && count + 1 == n_outer ? wit + lap_wit_word(slot) : nullptr;
+                unsigned* const w_now = guard && !exhaustive && count + 1 == n_outer ? wit + lap_wit_word(slot) : nullptr;
                 PAPOF_TRY(update_warp_phi(h, sp, uv, uv + np, uv2, uv2 + np, f1, f2, nullptr, nullptr, lh, lw, fc, false, 0, -1,
                                           w_now, B, &bk));
                 std::swap(uv, uv2);
+                if (exhaustive) PAPOF_TRY(lap_small_check(h, f1, f2, uv, uv + np, lh, lw, fc, wit + lap_wit_word(slot), B, &bk));
                 slot_level.push_back(k);
                 slot++;
             }
@@ -256,7 +262,8 @@ int flow_batch_device(papof_handle* h, int B, int sequence, const void* const* f
             const int fa = p * fstep, fb = fa + 1;
             for (int s = 0; s + 1 < slot && open; s++)  // the estimate behind the call's last update is never consulted
                 for (int c = 0; c < fc; c++) {
-                    const bool witness = hw[(size_t)p * kLapFlagWords + lap_wit_word(s) + c] == epoch;
+                    const unsigned w = hw[(size_t)p * kLapFlagWords + lap_wit_word(s) + c];
+                    const bool witness = w == epoch || w == (epoch ^ kLapNone);  // a sample, or an exhaustive "no valid sample at all"
                     const size_t nzw = (size_t)slot_level[s] * 8 + c;
                     const bool all_zero = nz_known && hn[(size_t)fa * kLapNzWords + nzw] != epoch &&
                                           hn[(size_t)fb * kLapNzWords + nzw] != epoch;

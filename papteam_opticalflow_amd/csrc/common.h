@@ -398,7 +398,8 @@ int lap_rows_check(papof_handle* h, const double* im1, const double* im2, const 
                    int C, int r0, int r1, unsigned* wit, unsigned* val, unsigned mark);  // rows r0 .. r1-1, every pixel
 bool lap_one_block_level(int H, int W);  // k_warp_smooth_blend runs one block per channel: exhaustive check of the guard
 int lap_small_check(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H, int W,
-                    int C, unsigned* wit);  // the same check for the flow behind the last update of such a level
+                    int C, unsigned* wit, int batch = 1, const BatchK* bk = nullptr);  // the same check (EVERY pixel: a witness, or
+                                                                                     // "no valid sample at all") for a given flow
 int est_laplacian_noise(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H,
                         int W, int C, double* lap, double* scratch);  // the exact pass of the Laplacian-noise guard
 int gm_scratch_doubles();

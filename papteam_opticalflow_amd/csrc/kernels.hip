@@ -2151,8 +2151,17 @@ static __global__ void k_lap_finish(const double* __restrict__ partial, int C, d
 // level (nobody evaluates the warp at that flow): one block per channel over every pixel.
 static __global__ __launch_bounds__(256) void k_lap_small(const double* __restrict__ im1, const double* __restrict__ im2,
                                                        const double* __restrict__ u, const double* __restrict__ v, int H,
-                                                       int W, unsigned* __restrict__ wit, double wit_thr, unsigned mark) {
+                                                       int W, unsigned* __restrict__ wit, double wit_thr, unsigned mark,
+                                                       BatchK bk) {
     const int np = H * W;
+    {   // blockIdx.y: the pair of a batch (common.h: BatchK)
+        const size_t p = blockIdx.y;
+        im1 += p * bk.im;
+        im2 += p * bk.im;
+        u += p * bk.uv;
+        v += p * bk.uv;
+        wit += p * bk.wit;
+    }
     const double *p1 = im1 + (size_t)blockIdx.x * np, *p2 = im2 + (size_t)blockIdx.x * np;
     bool hit = false, valid = false;
     for (int o = threadIdx.x; o < np; o += 256) {
@@ -2199,9 +2208,10 @@ int lap_rows_check(papof_handle* h, const double* im1, const double* im2, const 
 }
 bool lap_one_block_level(int H, int W) { return H <= kWsRows && W <= BX; }
 int lap_small_check(papof_handle* h, const double* im1, const double* im2, const double* u, const double* v, int H, int W,
-                    int C, unsigned* wit) {
-    hipLaunchKernelGGL(k_lap_small, dim3(C), dim3(256), 0, h->stream, im1, im2, u, v, H, W, wit,
-                       2e-20 * (double)H * (double)W, h->lap_epoch);
+                    int C, unsigned* wit, int batch, const BatchK* bk) {
+    const BatchK bk0{0, 0, 0, 0, 0, 0};
+    hipLaunchKernelGGL(k_lap_small, dim3(C, batch), dim3(256), 0, h->stream, im1, im2, u, v, H, W, wit,
+                       2e-20 * (double)H * (double)W, h->lap_epoch, bk ? *bk : bk0);
     LAUNCH_CHECK();
     return PAPOF_OK;
 }

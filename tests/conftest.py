@@ -45,7 +45,20 @@ def tile_group(request, monkeypatch):
         yield capi.LocalTileGroup
         return
     assert os.path.exists(FAKE_RCCL), "tests/fake_rccl/libfake_rccl.so is not built (__graft_entry__.build())"
+    # The ranks' group kernels wait for each other on the device, so every rank's stream needs a hardware queue of its own (see the
+    # top of this file): give back the streams that earlier tests left pooled -- flow_collection()'s handles, the default handle
+    import gc
+    import papteam_opticalflow_amd as pkg
+    for pool in pkg._collection_handles.values():
+        for hnd in pool:
+            hnd.close()
+        pool.clear()
+    if pkg._default is not None:
+        pkg._default.close()
+        pkg._default = None
+    gc.collect()
     monkeypatch.setenv("PAPOF_RCCL_LIB", FAKE_RCCL)
+    monkeypatch.setenv("PAPOF_TILES_TIMEOUT_S", os.environ.get("PAPOF_TILES_TIMEOUT_S", "40"))
     fake = ctypes.CDLL(FAKE_RCCL)
     fake.fake_rccl_error_count.restype = ctypes.c_uint
     fake.fake_rccl_reset_errors()

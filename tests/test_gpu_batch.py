@@ -92,7 +92,9 @@ def test_deep_pyramid_batch_and_what_the_chain_does_not_cover(gpu):
     entry point, same bits as the single calls."""
     from papteam_opticalflow_amd import default_params
     frames = _video("240", 3)
+    before = gpu.lap_guard_stats()["reruns"]
     out, _ = gpu.flow_batch(frames, 15, None, sequence=True)
+    assert gpu.lap_guard_stats()["reruns"] == before, "few-pixel levels: the exhaustive check must prove the guard open, no re-run"
     for i in range(2):
         _same(out[i], gpu.coarse2fine_flow_u8(frames[i], frames[i + 1], 15)[:3], "15 levels, pair %d" % i)
     P = default_params(sor_mode=1)
