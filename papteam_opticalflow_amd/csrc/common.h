@@ -455,7 +455,7 @@ struct SorSplit {
     bool top_cut, bot_cut;
 };
 int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor,
-                    unsigned* prog, int b0, int b1, const SorSplit* split = nullptr);
+                    unsigned* prog, int b0, int b1, const SorSplit* split = nullptr, int k0 = 0, int k1 = -1);  // sweeps k0 .. k1-1 (split only)
 int sor_bind_plain(papof_handle* h, SorPlanes& sp, int H, int W, int n_sor);
 bool sor_tiny_fits(const papof_handle* h, int H, int W, int n_sor);
 constexpr size_t kTinyMaxCells = 8192;  // upper bound of what sor_tiny_fits() accepts (registers of one workgroup)

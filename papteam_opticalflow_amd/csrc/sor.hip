@@ -2428,8 +2428,11 @@ int sor_strips_begin(papof_handle* h, const SorPlanes& sp, int n_sor, int n_solv
 }
 
 int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, double omega, int n_sor,
-                    unsigned* prog, int b0, int b1, const SorSplit* split) {
-    if (!sp.skew || n_sor <= 0) return PAPOF_EINVAL;
+                    unsigned* prog, int b0, int b1, const SorSplit* split, int k0, int k1) {
+    // k0 .. k1-1: the sweeps of THIS launch (split solves only: tiles.hip issues a rank's solve as launches over ranges of
+    // sweeps so that the ranks pipeline; the ping-pong planes and the counters carry the state from launch to launch)
+    if (k1 < 0) k1 = n_sor;
+    if (!sp.skew || n_sor <= 0 || k0 < 0 || k1 > n_sor || k1 <= k0 || ((k0 != 0 || k1 != n_sor) && !split)) return PAPOF_EINVAL;
     // split over handles (tiles.hip: bands_flow): the plain kernel only, one inbox cell per sweep (ExactArgs)
     if (split && (sp.sd.fuse != 1 || sp.sd.group != 1 || n_sor > 128 || !h->use_dpp)) return PAPOF_EINVAL;
     const SkewDims sd = skew_dims(H, W, n_sor, sp.sd.group, sp.sd.fuse);
@@ -2443,7 +2446,7 @@ int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double a
     const int nbl = b1 - b0;
     if (std::getenv("PAPOF_SOR_INJECT_ABORT"))  // fault injection for the tests, as in sor_solve
         PAPOF_HIP(hipMemsetAsync(h->sync_words, 1, sizeof(unsigned), h->stream));
-    {
+    if (k0 == 0) {  // (once per solve: later launches of the solve read what the earlier ones wrote)
         const unsigned n16 = (unsigned)(2 * sd.npos_d) * (unsigned)nbl * kLanes;
         hipLaunchKernelGGL(k_sor_clear_bands, dim3((n16 + 255) / 256), dim3(256), 0, h->stream, (uint4*)sp.du, sd.nb, b0,
                            nbl, n16);
@@ -2471,7 +2474,7 @@ int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double a
     A.n_sor = n_sor;
     A.nalpha = -alpha;
     A.om1 = 1 - omega;
-    A.k0 = 0;
+    A.k0 = k0;
     A.b0 = b0;
     A.nbl = nbl;
     A.xcd_affine = 0;
@@ -2486,7 +2489,7 @@ int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double a
     if (h->sor_mark) h->sor_mark(h->sor_mark_ctx, 1);
     if (split) {
         const int R = h->sor_depth > 0 ? h->sor_depth : (sd.nb >= 8 ? 8 : 6);
-        const dim3 grid(nbl * n_sor);
+        const dim3 grid(nbl * (k1 - k0));
         if (R <= 6)
             hipLaunchKernelGGL((k_sor_exact<6, true, true>), grid, dim3(kLanes), 0, h->stream, A);
         else

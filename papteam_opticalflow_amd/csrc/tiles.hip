@@ -380,8 +380,8 @@ __global__ void k_rects(MsgTable t, double* __restrict__ buf) {
 // position p the 16-byte cell k >> 1 of block `band` at parity k & 1 of banded (du, dv) planes (sor.hip: ExactArgs) <->
 // msg[k * npos + p].  PACK reads the producer's outbox planes, else the cells go into the consumer's planes.
 template <bool PACK>
-__global__ void k_cut_cells(double2* __restrict__ planes, double2* __restrict__ msg, int nb, int npos, int band, int K) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+__global__ void k_cut_cells(double2* __restrict__ planes, double2* __restrict__ msg, int nb, int npos, int band, int k0, int K) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, k = k0 + blockIdx.y;  // sweeps k0 .. K-1 of the solve (one chunk)
     if (p >= npos || k >= K) return;
     const size_t cell = (size_t)(k & 1) * npos * nb * kLanes + ((size_t)p * nb + band) * kLanes + (size_t)(k >> 1);
     if (PACK)
@@ -390,8 +390,8 @@ __global__ void k_cut_cells(double2* __restrict__ planes, double2* __restrict__ 
         planes[cell] = msg[(size_t)k * npos + p];
 }
 // ... and the producer's progress counters as the consumer then finds them: every sweep of the band above complete
-__global__ void k_cut_counters(unsigned* __restrict__ prog, int nb, int band, int K, unsigned steps) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_cut_counters(unsigned* __restrict__ prog, int nb, int band, int k0, int K, unsigned steps) {
+    const int k = k0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (k < K) prog[((size_t)k * nb + band) * 32] = steps;
 }
 
@@ -887,6 +887,8 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
     // by construction with nothing but sends and receives at kernel boundaries, and necessarily slower than one GPU for the
     // solver's share (the exact-order solve is one dependency chain); everything else still splits over the ranks.
     const bool direct = t.tp->addresses_peers();
+    // staged protocol: launches (= messages per cut) per solve; 1 = the ranks take turns (see the staged branch below)
+    const int bands_chunks = std::getenv("PAPOF_BANDS_CHUNKS") ? std::max(1, std::atoi(std::getenv("PAPOF_BANDS_CHUNKS"))) : 1;
     std::vector<void*> arenas(n, nullptr), syncs(n, nullptr);
     double* outbox = nullptr;       // STAGED: banded planes (same layout) that receive the SPLIT kernel's peer stores
     unsigned* outprog = nullptr;    // ... and its peer publications (discarded)
@@ -1032,40 +1034,56 @@ int bands_flow(papof_tiles& t, const double* d_im1, const double* d_im2, int H, 
                     t.tp->turn_done(solve_no);
                 }
             }
-            if (!direct) {  // STAGED: round r hands the cut cells of rank r's finished bands to rank r + 1
+            if (!direct) {
+                // STAGED.  The solve of every rank is issued as `chunks` launches over ranges of sweeps [k0, k1); the cut cells of a
+                // range travel to the rank below as soon as its launch has ended, so rank g + 1 runs sweeps [k0, k1) while rank g
+                // runs [k1, k2).  chunks = 1 (the default): the ranks take turns within a solve.  In stream order on rank g, per
+                // range: receive the range's cut cells from g - 1, unpack them into the inbox cells and mark those sweeps of the
+                // band above complete, launch the own bands for the range, pack and send the own last band's cut cells to g + 1.
+                // What it buys is modelled in DESIGN.md 7 (every range pays a full row traversal: little) and can be measured with
+                // PAPOF_BANDS_CHUNKS on a multi-GPU node; results are the same bits for every chunk count (tests/test_gpu_bands.py).
                 const int m_ranks = std::min(n, sp.sd.nb);  // ranks with bands: 0 .. m_ranks - 1
                 const int npos = sp.sd.npos_d;
-                const size_t msg_doubles = (size_t)2 * K * npos;
                 unsigned* const prog = h->sync_words + 32 + LP[k].off + (size_t)count * LP[k].per;
                 SorSplit cut{below >= 0 ? outbox : nullptr, below >= 0 ? outprog : nullptr, B0 > 0, below >= 0};
-                const dim3 cgrid((npos + 255) / 256, K), cblock(256);
-                const auto solve_mine = [&]() -> int {
+                const int chunks = std::max(1, std::min(bands_chunks, K));
+                const auto launch_range = [&](int k0, int k1) -> int {
                     sorclk.phase(PAPOF_T_PHASE5_SOR);
-                    if (!silent) PAPOF_TRY(sor_solve_bands(h, sp, lh, lw, P.alpha, P.omega, K, prog, B0, B1, &cut));
+                    if (!silent) PAPOF_TRY(sor_solve_bands(h, sp, lh, lw, P.alpha, P.omega, K, prog, B0, B1, &cut, k0, k1));
                     sorclk.phase(-1);
                     return PAPOF_OK;
                 };
-                if (mine && me == 0) PAPOF_TRY(solve_mine());
-                for (int r = 0; r + 1 < m_ranks; r++) {
-                    std::vector<Msg> sends, recvs;
-                    if (me == r && !silent) {  // (fault injection: a silent rank never sends its cut cells either)
-                        hipLaunchKernelGGL(k_cut_cells<true>, cgrid, cblock, 0, h->stream, (double2*)outbox, (double2*)cutmsg,
-                                           sp.sd.nb, npos, B1 - 1, K);
-                        PAPOF_HIP(hipGetLastError());
-                        sends.push_back(Msg{r + 1, cutmsg, msg_doubles});
-                    } else if (me == r + 1) {
-                        recvs.push_back(Msg{r, cutmsg, msg_doubles});
-                    }
-                    PAPOF_TRY(t.tp->exchange(h, sends, recvs));
-                    t.exchanges++;
-                    t.exchanged_bytes += (sends.size() + recvs.size()) * msg_doubles * sizeof(double);
-                    if (me == r + 1) {
-                        hipLaunchKernelGGL(k_cut_cells<false>, cgrid, cblock, 0, h->stream, (double2*)sp.du, (double2*)cutmsg,
-                                           sp.sd.nb, npos, B0 - 1, K);
-                        hipLaunchKernelGGL(k_cut_counters, dim3((K + 63) / 64), dim3(64), 0, h->stream, prog, sp.sd.nb, B0 - 1, K,
-                                           (unsigned)sp.sd.ns);
-                        PAPOF_HIP(hipGetLastError());
-                        PAPOF_TRY(solve_mine());
+                for (int c = 0; c < chunks; c++) {
+                    const int k0 = (int)((long long)K * c / chunks), k1 = (int)((long long)K * (c + 1) / chunks);
+                    if (k1 <= k0) continue;
+                    const size_t msg_doubles = (size_t)2 * (k1 - k0) * npos;
+                    double* const msg = cutmsg + (size_t)2 * k0 * npos;  // (k_cut_cells indexes the message by absolute sweep)
+                    const dim3 cgrid((npos + 255) / 256, k1 - k0), cblock(256);
+                    if (mine && me == 0) PAPOF_TRY(launch_range(k0, k1));
+                    // round (c, r): rank r hands the range's cut cells to rank r + 1.  EVERY rank walks every round (a transport
+                    // whose exchanges are collective -- LOCAL -- needs that; on RCCL a round without a message costs nothing), so
+                    // on rank g the stream holds, per range: receive (round g - 1), unpack, launch, pack, send (round g).
+                    for (int r = 0; r + 1 < m_ranks; r++) {
+                        std::vector<Msg> sends, recvs;
+                        if (me == r && !silent) {  // (fault injection: a silent rank never sends its cut cells either)
+                            hipLaunchKernelGGL(k_cut_cells<true>, cgrid, cblock, 0, h->stream, (double2*)outbox, (double2*)cutmsg,
+                                               sp.sd.nb, npos, B1 - 1, k0, k1);
+                            PAPOF_HIP(hipGetLastError());
+                            sends.push_back(Msg{r + 1, msg, msg_doubles});
+                        } else if (me == r + 1) {
+                            recvs.push_back(Msg{r, msg, msg_doubles});
+                        }
+                        PAPOF_TRY(t.tp->exchange(h, sends, recvs));
+                        t.exchanges++;
+                        t.exchanged_bytes += (sends.size() + recvs.size()) * msg_doubles * sizeof(double);
+                        if (me == r + 1) {
+                            hipLaunchKernelGGL(k_cut_cells<false>, cgrid, cblock, 0, h->stream, (double2*)sp.du, (double2*)cutmsg,
+                                               sp.sd.nb, npos, B0 - 1, k0, k1);
+                            hipLaunchKernelGGL(k_cut_counters, dim3((k1 - k0 + 63) / 64), dim3(64), 0, h->stream, prog, sp.sd.nb,
+                                               B0 - 1, k0, k1, (unsigned)sp.sd.ns);
+                            PAPOF_HIP(hipGetLastError());
+                            PAPOF_TRY(launch_range(k0, k1));
+                        }
                     }
                 }
             }

@@ -121,6 +121,39 @@ def test_staged_protocol_of_the_rccl_transport_gives_the_same_bits(gpu, monkeypa
     assert n_ex > 0
 
 
+@pytest.mark.parametrize("chunks,nranks,res,levels,kw", [
+    (3, 2, "960", 5, dict(n_outer=3, n_outer_per_level=0, n_sor=30, n_sor_per_level=0)),
+    (4, 8, "480", 5, {}),
+    (7, 3, "240", 4, dict(n_outer=2, n_outer_per_level=1, n_sor=9, n_sor_per_level=4)),
+    (64, 5, "240", 2, dict(n_outer=2, n_outer_per_level=0, n_sor=5, n_sor_per_level=3)),   # more chunks than sweeps: one sweep per launch
+])
+def test_staged_protocol_in_ranges_of_sweeps_gives_the_same_bits(gpu, monkeypatch, tile_group, chunks, nranks, res, levels, kw):
+    """the staged protocol issues every rank's solve as launches over ranges of sweeps
+    (PAPOF_BANDS_CHUNKS) and sends the cut cells of a range as soon as its launch has ended, so that rank g + 1 runs sweeps
+    [k0, k1) while rank g runs [k1, k2).  Same bits as the one-GPU exact call for any number of ranges, on the LOCAL transport
+    (forced staged) and on the RCCL transport bound to the stand-in, where nothing but stream order holds the ranges apart."""
+    monkeypatch.setenv("PAPOF_BANDS_STAGED", "1")
+    monkeypatch.setenv("PAPOF_BANDS_CHUNKS", str(chunks))
+    a, b = cases.load_pair(res)
+    P = _params(**kw)
+    want = gpu.coarse2fine_flow(a, b, levels, P)[:3]
+    (vx, vy, wi, _), (n_ex, _) = _run(nranks, a, b, levels, P, tile_group)
+    for name, g, w in zip(("vx", "vy", "warpI2"), (vx, vy, wi), want):
+        assert np.array_equal(g, w), "%d ranges, %d ranks %s L%d %s: max-abs %.3e" % (chunks, nranks, res, levels, name, np.abs(g - w).max())
+
+
+def test_chunked_staged_split_returns_the_reference_bits_at_1080p(monkeypatch, tile_group):
+    """... and at size: 8 ranks, 3 ranges of sweeps per solve, the reference's golden of the 1920x1080 config-4 pair (full-array SHA)."""
+    monkeypatch.setenv("PAPOF_BANDS_STAGED", "1")
+    monkeypatch.setenv("PAPOF_BANDS_CHUNKS", "3")
+    a, b = cases.load_pair("1920")
+    kw = dict(n_outer=3, n_outer_per_level=0, n_sor=30, n_sor_per_level=0)
+    (vx, vy, wi, _), _ = _run(8, a, b, 5, _params(**kw), tile_group)
+    man = json.load(open(os.path.join(GOLD, "golden.json")))["cases"]["cfg4_1920_L5"]
+    for name, got in (("vx", vx), ("vy", vy), ("warpI2", wi)):
+        assert cases.sha(got) == man[name]["sha"], "cfg4_1920_L5/%s: full-array SHA-256 differs from the reference's" % name
+
+
 def test_exact_split_over_the_rccl_transport_with_one_rank(gpu):
     """The RCCL transport itself with sor_mode = 0 (a group of one: no cut, no sends -- the plumbing and the dispatch)."""
     from papteam_opticalflow_amd import capi
