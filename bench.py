@@ -380,11 +380,13 @@ def main():
             launches = gpu.last_sor_stats()[0] or launches      # of bands issue one launch per strip and solve)
         sor_step = sor_sec / args.steps
         achieved = updates * BYTES_PER_UPDATE / 1e9 / sor_step if sor_step > 0 else 0.0
-        traffic = None
+        traffic, traffic_by_grid = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("%s_%s_%s" % (args.res, args.schedule, args.mode))
+                tj = json.load(open(tpath))
+                traffic = tj.get("%s_%s_%s" % (args.res, args.schedule, args.mode))
+                traffic_by_grid = (tj.get("%s_%s_%s_detail" % (args.res, args.schedule, args.mode)) or {}).get("by_grid_finest_first")
             except Exception:
                 traffic = None
         # per level and per kernel: the solver kernels' own HIP-event time of every solve, as the library recorded it
@@ -405,6 +407,15 @@ def main():
             k["launches"] += n_launch
             k["sec"] += sec
             k["gbytes"] += gbytes
+        # per-level HBM-side traffic from this round's PMC passes (profiles/pmc_traffic.json: by_grid_finest_first; STATIC, as
+        # roofline.traffic): the levels finest first are the solver's launch grids largest first -- attached when the counts agree
+        if traffic_by_grid and len(traffic_by_grid) == len(by_level) and all(e["launches"] == e["solves"] for e in by_level):
+            for e, g in zip(by_level, traffic_by_grid):
+                if e["kernel"].split("<")[0] != g["kernel"].split("<")[0]:
+                    break
+                e["traffic"] = g["bytes_per_launch"]
+                e["traffic_over_algorithmic"] = round(g["bytes_per_launch"] / (e["achieved"] * 1e9 * e["avg_launch_us"] * 1e-6), 3)
+                e["frac_on_traffic"] = round(g["bytes_per_launch"] / (e["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         by_kernel = {n: {"launches": v["launches"], "avg_launch_us": round(v["sec"] / v["launches"] * 1e6, 1),
                          "share_of_sor_time": round(v["sec"] / max(sor_sec, 1e-30), 4),
                          "achieved": round(v["gbytes"] / v["sec"], 1), "frac": round(v["gbytes"] / v["sec"] / HBM_PEAK_GBS, 4)}

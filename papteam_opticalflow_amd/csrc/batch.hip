@@ -317,6 +317,28 @@ int flow_batch_host(papof_handle* h, int n_pairs, int sequence, const void* cons
         if (timing_sec) std::memcpy(timing_sec, tm, sizeof tm);
         return PAPOF_OK;
     }
+    // One launch of the solver holds the tasks of ALL pairs, and all of them must be resident (sor.hip: resident_tasks): a
+    // collection larger than that -- or than a few GB of arena -- goes through in sub-batches of the same shape.
+    {
+        const int nb0 = skew_dims(H, W, P.n_sor + (levels - 1) * P.n_sor_per_level, 1, 1).nb;
+        const size_t per_pair = arena_bytes_for(H, W, C, levels, P.n_sor + (levels - 1) * P.n_sor_per_level, P.ratio);
+        int max_b = (int)std::max<size_t>(2, std::min<size_t>((size_t)1024 / (size_t)nb0, ((size_t)24 << 30) / per_pair));
+        if (const char* e = std::getenv("PAPOF_BATCH_MAX")) max_b = std::max(2, std::min(max_b, std::atoi(e)));  // (and the tests')
+        if (n_pairs > max_b) {
+            const int step = sequence ? 1 : 2;
+            for (int p0 = 0; p0 < n_pairs;) {
+                int nb_ = std::min(max_b, n_pairs - p0);
+                if (n_pairs - (p0 + nb_) == 1 && nb_ > 2) nb_ -= 1;  // leave two pairs for the last sub-batch rather than one
+                double t1[PAPOF_N_TIMERS];
+                PAPOF_TRY(flow_batch_host(h, nb_, sequence, frames + (size_t)p0 * step, u8, H, W, C, levels, &P, vx + p0, vy + p0,
+                                          warpI2 + p0, t1));
+                for (int i = 0; i < PAPOF_N_TIMERS; i++) tm[i] += t1[i];
+                p0 += nb_;
+            }
+            if (timing_sec) std::memcpy(timing_sec, tm, sizeof tm);
+            return PAPOF_OK;
+        }
+    }
     BatchOut out;
     PAPOF_TRY(flow_batch_device(h, n_pairs, sequence, frames, u8, H, W, C, levels, P, tm, out));
     const size_t np0 = (size_t)H * W;

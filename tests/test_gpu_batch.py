@@ -138,3 +138,20 @@ def test_flow_collection_batched_equals_unbatched(gpu):
     assert sorted(seen) == list(range(11))
     for i in range(11):
         _same(seen[i], want[i][1:], "on_pair %d" % i)
+
+
+def test_a_collection_larger_than_one_launch_holds_goes_through_in_sub_batches(gpu, monkeypatch):
+    """More pairs than one launch of the solver may hold go through in sub-batches (their size follows the band count and the
+    arena; PAPOF_BATCH_MAX caps it -- 3 here: 7 pairs as 3 + 2 + 2, never a batch of one): same bits, pair for pair.  A frame too
+    tall for the batched chain (>= 16 solver bands) runs as single calls through the same entry point."""
+    frames = _video("240", 8)
+    monkeypatch.setenv("PAPOF_BATCH_MAX", "3")
+    out, _ = gpu.flow_batch(frames, 3, None, sequence=True)
+    monkeypatch.delenv("PAPOF_BATCH_MAX")
+    assert len(out) == 7
+    for i in range(7):
+        _same(out[i], gpu.coarse2fine_flow_u8(frames[i], frames[i + 1], 3)[:3], "sub-batched pair %d" % i)
+    tall = [np.ascontiguousarray(np.tile(f, (8, 1, 1))[:1000, :64]) for f in frames[:3]]  # 1000 rows: 17 bands
+    out, _ = gpu.flow_batch(tall, 2, None, sequence=True)
+    for i in range(2):
+        _same(out[i], gpu.coarse2fine_flow_u8(tall[i], tall[i + 1], 2)[:3], "tall frame, pair %d" % i)

@@ -35,6 +35,19 @@ def main():
            "fetch_kib_raw_avg": sum(f) / len(f), "write_kib_avg": sum(w) / len(w),
            "bytes_per_launch": int((2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024),
            "note": "FETCH_SIZE doubled (gfx950 half-count of wide coalesced reads); includes Infinity-Cache hits"}
+    # per LEVEL: the solver launches of a call differ in grid size by pyramid level (one launch per solve at these sizes), so
+    # the averages per (kernel, grid), largest grid first, are the levels finest first -- bench.py's roofline.by_level[*].traffic
+    if fetch_csv.endswith(".db") and write_csv.endswith(".db"):
+        import sqlite3
+        q = ("select kernel_name, grid_size, avg(value), count(*) from counters_collection where counter_name = ? and "
+             "kernel_name like ? group by kernel_name, grid_size")
+        fg = {(r[0], r[1]): (r[2], r[3]) for r in sqlite3.connect(fetch_csv).execute(q, ("FETCH_SIZE", "%" + kernel + "%"))}
+        wg = {(r[0], r[1]): (r[2], r[3]) for r in sqlite3.connect(write_csv).execute(q, ("WRITE_SIZE", "%" + kernel + "%"))}
+        short = lambda n: n.replace("papof::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        out["by_grid_finest_first"] = [
+            {"kernel": short(k[0]), "grid_threads": k[1], "launches_sampled": fg[k][1],
+             "bytes_per_launch": int((2.0 * fg[k][0] + wg[k][0]) * 1024)}
+            for k in sorted(fg, key=lambda k: -k[1]) if k in wg]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "profiles", "pmc_traffic.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
