@@ -409,13 +409,24 @@ def main():
             k["gbytes"] += gbytes
         # per-level HBM-side traffic from this round's PMC passes (profiles/pmc_traffic.json: by_grid_finest_first; STATIC, as
         # roofline.traffic): the levels finest first are the solver's launch grids largest first -- attached when the counts agree
-        if traffic_by_grid and len(traffic_by_grid) == len(by_level) and all(e["launches"] == e["solves"] for e in by_level):
-            for e, g in zip(by_level, traffic_by_grid):
-                if e["kernel"].split("<")[0] != g["kernel"].split("<")[0]:
-                    break
-                e["traffic"] = g["bytes_per_launch"]
-                e["traffic_over_algorithmic"] = round(g["bytes_per_launch"] / (e["achieved"] * 1e9 * e["avg_launch_us"] * 1e-6), 3)
-                e["frac_on_traffic"] = round(g["bytes_per_launch"] / (e["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        if traffic_by_grid and all(e["launches"] == e["solves"] for e in by_level):
+            def norm(n):  # "k_sor_exact<8, true, false>" -> "k_sor_exact<8>"
+                return n.split("<")[0] + "<" + n.split("<")[1].split(",")[0].rstrip(">") + ">" if "<" in n else n
+            pm = {}
+            for g in traffic_by_grid:
+                pm.setdefault(norm(g["kernel"]), []).append(g)
+            lv = {}
+            for e in by_level:
+                lv.setdefault(e["kernel"], []).append(e)
+            for name, es in lv.items():  # same kernel: larger plane = larger launch grid
+                gs = sorted(pm.get(name, []), key=lambda g: -g["grid_threads"])
+                if len(gs) != len(es):
+                    continue
+                for e, g in zip(es, gs):  # (by_level is sorted by plane size already)
+                    alg = int(e["level"].split("x")[0]) * int(e["level"].split("x")[1]) * e["sweeps"] * BYTES_PER_UPDATE
+                    e["traffic"] = g["bytes_per_launch"]
+                    e["traffic_over_algorithmic"] = round(g["bytes_per_launch"] / alg, 3)
+                    e["frac_on_traffic"] = round(g["bytes_per_launch"] / (e["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         by_kernel = {n: {"launches": v["launches"], "avg_launch_us": round(v["sec"] / v["launches"] * 1e6, 1),
                          "share_of_sor_time": round(v["sec"] / max(sor_sec, 1e-30), 4),
                          "achieved": round(v["gbytes"] / v["sec"], 1), "frac": round(v["gbytes"] / v["sec"] / HBM_PEAK_GBS, 4)}

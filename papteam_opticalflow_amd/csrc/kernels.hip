@@ -275,7 +275,7 @@ __global__ void k_im2feature(const double* __restrict__ im, double* __restrict__
 #define PAPOF_V_FEATROWS 16
 #endif
 constexpr int kFeatRows = PAPOF_V_FEATROWS;
-template <int C>
+template <int C, bool BATCH = false>
 __global__ __launch_bounds__(256) void k_im2feature_tiled(const double* __restrict__ im, double* __restrict__ feat, int H,
                                                           int W, Taps d, unsigned* __restrict__ nz, unsigned mark,
                                                           size_t b_im, size_t b_feat, size_t b_nz) {
@@ -287,9 +287,11 @@ __global__ __launch_bounds__(256) void k_im2feature_tiled(const double* __restri
     if (!xcd_tile((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows, tx, ty)) return;  // whole workgroup, before any barrier
     const int j0 = tx * BX, i0 = ty * kFeatRows;
     const size_t np = (size_t)H * W;
-    im += blockIdx.y * b_im;  // blockIdx.y: the frame of a batch (common.h: BatchK)
-    feat += blockIdx.y * b_feat;
-    if (nz != nullptr) nz += blockIdx.y * b_nz;
+    if (BATCH) {  // blockIdx.y: the frame of a batch (common.h: BatchK)
+        im += blockIdx.y * b_im;
+        feat += blockIdx.y * b_feat;
+        if (nz != nullptr) nz += blockIdx.y * b_nz;
+    }
     for (int c = threadIdx.y * BX + threadIdx.x; c < (kFeatRows + 4) * (BX + 4); c += BX * BY) {
         const int r = c / (BX + 4), cc = c - r * (BX + 4);
         g[r][cc] = gray_at<C>(im, np, (size_t)clampi(i0 + r - 2, H) * W + clampi(j0 + cc - 2, W));
@@ -1001,14 +1003,14 @@ constexpr int kFT = 16, kFH = 4, kFW = kFT + 2 * kFH;  // tile, halo, tile with 
 struct SixPlanes {
     double* q[6];
 };
-template <int PLANES, bool SKEW>
+template <int PLANES, bool SKEW, bool BATCH = false>
 __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ im1, const double* __restrict__ im2,
                                                      const double* __restrict__ u, const double* __restrict__ v,
                                                      const double* __restrict__ im1s, int H, int W, double alpha,
                                                      double omega, SkewIdx sk, SixPlanes out, Taps g, Taps d,
                                                      unsigned long long* stamp, unsigned* __restrict__ wit, double wit_thr,
                                                      unsigned mark, int row0, int row1, BatchK bk) {
-    {   // blockIdx.y: the pair of a batch (common.h: BatchK)
+    if (BATCH) {  // blockIdx.y: the pair of a batch (common.h: BatchK)
         const size_t p = blockIdx.y;
         im1 += p * bk.im;
         im2 += p * bk.im;
@@ -1368,7 +1370,7 @@ __global__ void k_update_warp(const double* __restrict__ sdu, const double* __re
 // phi_out is given -- phi = 0.5 / sqrt(ux^2 + uy^2 + vx^2 + vy^2 + eps) of the NEW flow (src/OpticalFlow.cpp:295-331, the
 // expressions of k_phi) is written as well: u_new(i, j+1) = u(i, j+1) + du(i, j+1) is the same addition its own thread
 // performs, hence the same bits.  Saves one launch and one pass over (u, v) per outer iteration.
-template <bool SKEW>
+template <bool SKEW, bool BATCH = false>
 __global__ void k_update_warp_phi(const double* __restrict__ sdu, const double* __restrict__ sdv, SkewIdx sk,
                                   const double* __restrict__ u, const double* __restrict__ v,
                                   double* __restrict__ u_out, double* __restrict__ v_out,
@@ -1377,7 +1379,7 @@ __global__ void k_update_warp_phi(const double* __restrict__ sdu, const double* 
                                   int do_warp, unsigned long long* stamp, int row0, int row1, unsigned* __restrict__ wit,
                                   double wit_thr, unsigned mark, BatchK bk) {
     stamp_now(stamp);
-    {   // blockIdx.y: the pair of a batch (common.h: BatchK; warp and phi_out are not used there)
+    if (BATCH) {  // blockIdx.y: the pair of a batch (common.h: BatchK; warp and phi_out are not used there)
         const size_t p = blockIdx.y;
         sdu += p * bk.d;
         sdv += p * bk.d;
@@ -1483,12 +1485,14 @@ __global__ void k_update_warp_skew(const double2s* __restrict__ pd, double* __re
 // Corners A=(x0,y0) B=(x1,y0) C=(x0,y1) D=(x1,y1); cXY multiplies dx^X dy^Y; term order as in the
 // reference expressions.  Output goes straight to the interleaved HWC buffer handed back to the caller.
 // ------------------------------------------------------------------------------------------------
+template <bool BATCH>  // BATCH: blockIdx.y = the pair of a batch (a separate instantiation: the single call's code is untouched --
+                       // offsetting the pointers in the one kernel changed its register allocation and cost 47 us at 1080p)
 __global__ void k_bicubic(const double* __restrict__ im1, const double* __restrict__ im2,
                           const double* __restrict__ gx, const double* __restrict__ gy,
                           const double* __restrict__ gxy, const double* __restrict__ vx,
                           const double* __restrict__ vy, double* __restrict__ out, int H, int W, int C, Rect rc,
                           unsigned long long* stamp, int planar_out, int clamp, BatchK bk) {
-    {   // blockIdx.y: the pair of a batch (common.h: BatchK)
+    if (BATCH) {  // blockIdx.y: the pair of a batch (common.h: BatchK)
         const size_t p = blockIdx.y;
         im1 += p * bk.im;
         im2 += p * bk.im;
@@ -1791,10 +1795,10 @@ int im2feature(papof_handle* h, const double* im, double* feat, int H, int W, in
     // frames > 1 (a batch): frame f reads im + f * (C planes), writes feat + f * (5 or 3 planes), flags nz + f * nz_stride
     const size_t np = (size_t)H * W;
     if (C == 3) {
-        hipLaunchKernelGGL(k_im2feature_tiled<3>, dim3(xcd_grid((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows), frames), dim3(BX, BY), 0,
+        hipLaunchKernelGGL((frames > 1 ? k_im2feature_tiled<3, true> : k_im2feature_tiled<3, false>), dim3(xcd_grid((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows), frames), dim3(BX, BY), 0,
                            h->stream, im, feat, H, W, deriv5_taps(), nz, h->lap_epoch, 3 * np, 5 * np, nz_stride);
     } else if (C == 1) {
-        hipLaunchKernelGGL(k_im2feature_tiled<1>, dim3(xcd_grid((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows), frames), dim3(BX, BY), 0,
+        hipLaunchKernelGGL((frames > 1 ? k_im2feature_tiled<1, true> : k_im2feature_tiled<1, false>), dim3(xcd_grid((W + BX - 1) / BX, (H + kFeatRows - 1) / kFeatRows), frames), dim3(BX, BY), 0,
                            h->stream, im, feat, H, W, deriv5_taps(), nz, h->lap_epoch, np, 3 * np, nz_stride);
     } else {  // src/OpticalFlow.cpp:956-957: any other channel count is passed through
         if (frames != 1) return PAPOF_EINVAL;
@@ -1913,8 +1917,10 @@ int flow_system(papof_handle* h, const double* im1, const double* im2, const dou
     const dim3 grid(8 * ((ntiles + 7) / 8), batch);  // (the kernel maps block -> tile: a contiguous run of tiles per XCD)
     const SixPlanes six{{out.phi, out.xy, out.a1, out.a2, out.b1, out.b2}};
     const BatchK bk0{0, 0, 0, 0, 0, 0};
-    const auto kern = out.skew ? (planes == 5 ? k_flow_system<5, true> : k_flow_system<3, true>)
-                               : (planes == 5 ? k_flow_system<5, false> : k_flow_system<3, false>);
+    const auto kern = batch > 1 ? (out.skew ? (planes == 5 ? k_flow_system<5, true, true> : k_flow_system<3, true, true>)
+                                            : (planes == 5 ? k_flow_system<5, false, true> : k_flow_system<3, false, true>))
+                                : (out.skew ? (planes == 5 ? k_flow_system<5, true> : k_flow_system<3, true>)
+                                            : (planes == 5 ? k_flow_system<5, false> : k_flow_system<3, false>));
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, h->stream, im1, im2, u, v, im1s, H, W, alpha, omega,
                        out.skew ? skew_idx(out) : SkewIdx{0, 0, 0, 0, 0, 0, 0, 0, 0}, six, smooth5_taps(), deriv5_taps(),
                        take_stamp(h), wit, 2e-20 * (double)H * (double)W, h->lap_epoch, row0, row1, bk ? *bk : bk0);
@@ -1953,11 +1959,12 @@ int update_warp_phi(papof_handle* h, const SorPlanes& sp, const double* u, const
     if (row1 <= row0) return PAPOF_OK;
     const dim3 grid(xcd_grid((W + BX - 1) / BX, (row1 - row0 + BY - 1) / BY), batch);
     if (sp.skew)
-        hipLaunchKernelGGL(k_update_warp_phi<true>, grid, dim3(BX, BY), 0, h->stream, sp.du, sp.dv, skew_idx(sp),
+        hipLaunchKernelGGL((batch > 1 ? k_update_warp_phi<true, true> : k_update_warp_phi<true, false>), grid, dim3(BX, BY), 0,
+                           h->stream, sp.du, sp.dv, skew_idx(sp),
                            u, v, u_out, v_out, im1, im2, warp, phi_out, H, W, planes, do_warp ? 1 : 0, take_stamp(h),
                            row0, row1, wit, wit_thr, h->lap_epoch, bk ? *bk : bk0);
     else
-        hipLaunchKernelGGL(k_update_warp_phi<false>, grid, dim3(BX, BY), 0, h->stream, sp.du, sp.dv,
+        hipLaunchKernelGGL((batch > 1 ? k_update_warp_phi<false, true> : k_update_warp_phi<false, false>), grid, dim3(BX, BY), 0, h->stream, sp.du, sp.dv,
                            SkewIdx{0, 0, 0, 0, 0, 0, 0, 0, 0}, u, v, u_out, v_out, im1, im2, warp, phi_out, H, W, planes,
                            do_warp ? 1 : 0, take_stamp(h), row0, row1, wit, wit_thr, h->lap_epoch, bk ? *bk : bk0);
     LAUNCH_CHECK();
@@ -2005,7 +2012,7 @@ int bicubic_warp(papof_handle* h, const double* im1, const double* im2, const do
     const Rect r = region(rc, W, H);
     if (r.empty()) return PAPOF_OK;
     const BatchK bk0{0, 0, 0, 0, 0, 0};
-    hipLaunchKernelGGL(k_bicubic, dim3(xcd_grid((r.x1 - r.x0 + BX - 1) / BX, (r.y1 - r.y0 + BY - 1) / BY), batch), dim3(BX, BY), 0, h->stream, im1, im2, gx, gy, gxy, vx, vy, out_hwc, H, W,
+    hipLaunchKernelGGL(batch > 1 ? k_bicubic<true> : k_bicubic<false>, dim3(xcd_grid((r.x1 - r.x0 + BX - 1) / BX, (r.y1 - r.y0 + BY - 1) / BY), batch), dim3(BX, BY), 0, h->stream, im1, im2, gx, gy, gxy, vx, vy, out_hwc, H, W,
                        C, r, take_stamp(h), planar_out ? 1 : 0, clamp ? 1 : 0, bk ? *bk : bk0);
     LAUNCH_CHECK();
     return PAPOF_OK;
