@@ -1401,6 +1401,7 @@ int papof_create(int device, papof_handle** out) {
     if (const char* cs = std::getenv("PAPOF_RB_SHAPE")) h->rb_shape = std::max(0, std::atoi(cs));
     if (const char* cs = std::getenv("PAPOF_RB_NAIVE")) h->rb_naive = std::atoi(cs) != 0;
     if (const char* cs = std::getenv("PAPOF_SOR_RESIDENT")) h->sor_resident = std::max(0, std::atoi(cs));
+    if (const char* cs = std::getenv("PAPOF_SOR_DEAD")) h->sor_skip_dead = std::atoi(cs) != 0 ? 1 : 0;
     int rc = sor_probe_dpp(h);
     if (rc != PAPOF_OK) {
         papof_destroy(h);

@@ -279,6 +279,7 @@ struct papof_handle {
     int rb_shape = 0;                // ... region shape 1..4 (sor.hip: blocked_shape); 0 = by plane size
     int rb_naive = 0;                // 1: one launch per half-sweep on the planes (cross-check)
     int sor_resident = 0;            // tasks per launch of the exact-order kernels; 0 = 8 per CU (sor.hip: resident_tasks)
+    int sor_skip_dead = 1;           // k_sor_exact: lanes whose row lies outside the image neither load nor store (PAPOF_SOR_DEAD=0: A/B)
     unsigned* sor_prog_next = nullptr;  // cleared progress counters for the NEXT sor_solve() (else it clears its own)
     int sor_launches = 0;            // exact-order solver kernels launched by the current / last call (measurement: bench.py)
     // one entry per sor_solve() of the current / last call, in stream order (measurement: bench.py's roofline.by_level);

@@ -996,15 +996,19 @@ __global__ __launch_bounds__(256) void k_assemble_skew(const double* __restrict_
 // the tile.  phi of the tile (and its upper / left neighbours) is computed from (u, v) into LDS.  Every expression and its
 // order are those of the two kernels it replaces: same bits.
 // ------------------------------------------------------------------------------------------------
-constexpr int kFT = 16, kFH = 4, kFW = kFT + 2 * kFH;  // tile, halo, tile with halo
+constexpr int kFT = 16, kFH = 4, kFW = kFT + 2 * kFH;  // tile rows (and columns at TX = 16), halo, tile rows with halo
+#ifndef PAPOF_V_FS_TX
+#define PAPOF_V_FS_TX 16
+#endif
+constexpr int kFlowSystemTX = PAPOF_V_FS_TX;  // default tile width of k_flow_system (PAPOF_FS_TX overrides per process)
 // [163 registers: three workgroups per CU; forcing four or five waves per SIMD spills: 11.2 / 12.8 ms per 1080p pair against 10.35]
 // SKEW: the operands go to the exact-order solver's paired, skewed planes (pa, pb, pc); otherwise to six row-major planes
 // (q[0..5] = phi, xy, a1, a2, b1, b2: the one-workgroup solver of the small levels, k_sor_tiny).
 struct SixPlanes {
     double* q[6];
 };
-template <int PLANES, bool SKEW, bool BATCH = false>
-__global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ im1, const double* __restrict__ im2,
+template <int PLANES, bool SKEW, bool BATCH = false, int TX = 16>  // TX: columns of the tile (16 rows): 16 or 32; TX * 16 threads
+__global__ __launch_bounds__(TX * 16, TX == 32 ? 4 : 1) void k_flow_system(const double* __restrict__ im1, const double* __restrict__ im2,
                                                      const double* __restrict__ u, const double* __restrict__ v,
                                                      const double* __restrict__ im1s, int H, int W, double alpha,
                                                      double omega, SkewIdx sk, SixPlanes out, Taps g, Taps d,
@@ -1023,33 +1027,34 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
     }
     // rows row0 .. row1-1 are assembled (a rank's range of rows, tiles.hip: bands_flow; the whole plane otherwise): (u, v) are
     // read on rows row0 - 4 .. row1 + 3 only, the smoothed frame 1 on row0 - 2 .. row1 + 1
-    __shared__ double raw[kFW][kFW + 1];            // warped frame 2, pixels (ib - 4 .. ib + 19) x (j0 - 4 .. j0 + 19)
-    __shared__ double hs[kFW][kFT + 4 + 1];         // h-smoothed, columns j0 - 2 .. j0 + 17
-    __shared__ double bl[kFT + 4][kFT + 4 + 1];     // blend, pixels (ib - 2 .. ib + 17) x (j0 - 2 .. j0 + 17)
-    __shared__ double it[kFT][kFT + 1];             // imdt of the tile
-    __shared__ double ph[kFT + 1][kFT + 1 + 1];     // phi, pixels (ib - 1 .. ib + 15) x (j0 - 1 .. j0 + 15)
-    __shared__ double stage[6][kFT][kFT + 1];
+    constexpr int NT = TX * kFT, HWc = TX + 2 * kFH;  // threads = cells of the tile; columns of the tile with its halo
+    __shared__ double raw[kFW][HWc + 1];            // warped frame 2, pixels (ib - 4 .. ib + 19) x (j0 - 4 .. j0 + 19)
+    __shared__ double hs[kFW][TX + 4 + 1];         // h-smoothed, columns j0 - 2 .. j0 + 17
+    __shared__ double bl[kFT + 4][TX + 4 + 1];     // blend, pixels (ib - 2 .. ib + 17) x (j0 - 2 .. j0 + 17)
+    __shared__ double it[kFT][TX + 1];             // imdt of the tile
+    __shared__ double ph[kFT + 1][TX + 1 + 1];     // phi, pixels (ib - 1 .. ib + 15) x (j0 - 1 .. j0 + 15)
+    __shared__ double stage[6][kFT][TX + 1];
     stamp_now(stamp);
     // Workgroups are dealt round-robin over the 8 XCDs (observed; speed only): give each XCD a contiguous run of tiles, so
     // that the halo pixels neighbouring tiles both gather are found in that XCD's L2 (as k_sor_blocked does)
-    const int ntx = (W + kFT - 1) / kFT, ntiles = ntx * ((row1 - row0 + kFT - 1) / kFT), per = (ntiles + 7) >> 3;
+    const int ntx = (W + TX - 1) / TX, ntiles = ntx * ((row1 - row0 + kFT - 1) / kFT), per = (ntiles + 7) >> 3;
     const int vt = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= per || vt >= ntiles) return;  // whole workgroup, before any barrier
     const int tby = vt / ntx, tbx = vt - tby * ntx;
-    const int ib = row0 + tby * kFT, j0 = tbx * kFT, tid = threadIdx.x;
+    const int ib = row0 + tby * kFT, j0 = tbx * TX, tid = threadIdx.x;
     const size_t np = (size_t)H * W;
     const int vy0 = max(0, row0 - kFH), vy1 = min(H, row1 + kFH);  // rows on which the operands are valid
-    const bool interior = ib >= vy0 + kFH && ib + kFT <= row1 && ib + kFT + kFH <= vy1 && j0 >= kFH && j0 + kFT + kFH <= W;  // block-uniform
+    const bool interior = ib >= vy0 + kFH && ib + kFT <= row1 && ib + kFT + kFH <= vy1 && j0 >= kFH && j0 + TX + kFH <= W;  // block-uniform
     // ---- bilinear taps of the tile's pixels, once for all channels: (x0, y0), (dx, dy), or "outside" (frame 1's value)
-    constexpr int kPer = (kFW * kFW + 255) / 256;  // 3
+    constexpr int kPer = (kFW * HWc + NT - 1) / NT;  // 3 (TX = 16: 576 pixels, NT = 16 x 16), 2 (TX = 32: 960, NT = 32 x 16)
     int t_o[kPer], t_x0[kPer], t_y0[kPer];
     double t_dx[kPer], t_dy[kPer];
     bool t_in[kPer], t_out[kPer];
 #pragma unroll
     for (int q = 0; q < kPer; q++) {
-        const int c = tid + q * 256, r = c / kFW, cc = c - r * kFW;
+        const int c = tid + q * NT, r = c / HWc, cc = c - r * HWc;
         const int i = ib - kFH + r, j = j0 - kFH + cc;
-        t_in[q] = c < kFW * kFW && i >= vy0 && i < vy1 && j >= 0 && j < W;
+        t_in[q] = c < kFW * HWc && i >= vy0 && i < vy1 && j >= 0 && j < W;
         t_o[q] = t_in[q] ? i * W + j : 0;
         double x = 0.0, y = 0.0;  // (a cell outside the image: any valid position, its value is not used)
         t_out[q] = false;
@@ -1068,8 +1073,8 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
         t_dy[q] = y - t_y0[q];
     }
     // ---- phi of the tile and its upper / left neighbours (k_phi without an increment), and the flow of the own cell
-    for (int c = tid; c < (kFT + 1) * (kFT + 1); c += 256) {
-        const int r = c / (kFT + 1), cc = c - r * (kFT + 1);
+    for (int c = tid; c < (kFT + 1) * (TX + 1); c += NT) {
+        const int r = c / (TX + 1), cc = c - r * (TX + 1);
         const int i = ib - 1 + r, j = j0 - 1 + cc;
         if (i < 0 || i >= min(H, row1) || j < 0 || j >= W) continue;
         const size_t o = (size_t)i * W + j;
@@ -1090,7 +1095,7 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
         const double tt = ux * ux + uy * uy + vx * vx + vy * vy;
         ph[r][cc] = 0.5 / sqrt(tt + 0.001 * 0.001);
     }
-    const int orow = tid / kFT, ocol = tid - orow * kFT;  // this thread's cell of the tile
+    const int orow = tid / TX, ocol = tid - orow * TX;  // this thread's cell of the tile
     const int oi = ib + orow, oj = j0 + ocol;
     const bool own = oi < row1 && oj < W;
     double sxy = 0.0, sx2 = 0.0, sy2 = 0.0, stx = 0.0, sty = 0.0;
@@ -1100,7 +1105,7 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
     // The global operands of a channel are PREFETCHED while the previous channel is worked on (a workgroup barrier does not
     // wait for loads in flight): the gathers (or frame 1's value for a pixel that leaves the image) right behind P1, the smoothed
     // frame 1 of the blend's pixels right behind P3 -- the phases between are LDS only.
-    constexpr int kP3 = ((kFT + 4) * (kFT + 4) + 255) / 256;  // 2
+    constexpr int kP3 = ((kFT + 4) * (TX + 4) + NT - 1) / NT;  // 2
     double gv[kPer][4], s1v[kP3], wv = 0.0;
     const auto load_gathers = [&](int k) {
         const double *p1 = im1 + k * np, *p2 = im2 + k * np;
@@ -1120,7 +1125,7 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
         const double* ps = im1s + k * np;
 #pragma unroll
         for (int q = 0; q < kP3; q++) {  // (branch-free: a position outside the image reads its clamped pixel and is not used)
-            const int c = min(tid + q * 256, (kFT + 4) * (kFT + 4) - 1), r = c / (kFT + 4), cc = c - r * (kFT + 4);
+            const int c = min(tid + q * NT, (kFT + 4) * (TX + 4) - 1), r = c / (TX + 4), cc = c - r * (TX + 4);
             s1v[q] = ps[(size_t)clampi(ib - 2 + r, H) * W + clampi(j0 - 2 + cc, W)];
         }
     };
@@ -1132,7 +1137,7 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
         bool hit = false;
 #pragma unroll
         for (int q = 0; q < kPer; q++) {
-            const int c = tid + q * 256, r = c / kFW, cc = c - r * kFW;
+            const int c = tid + q * NT, r = c / HWc, cc = c - r * HWc;
             const double dx = t_dx[q], dy = t_dy[q], ex = 1.0 - dx, ey = 1.0 - dy;
             double res = 0.0;
             res += gv[q][0] * (ex * ey);
@@ -1154,16 +1159,16 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
         __syncthreads();
         // -- P2: horizontal pass on every row of the tile, columns j0 - 2 .. j0 + 17
         if (interior) {  // (block-uniform: every pixel of the tile + 4 is inside the image -- no clamps, no tests)
-            for (int c = tid; c < kFW * (kFT + 4); c += 256) {
-                const int r = c / (kFT + 4), cc = c - r * (kFT + 4);
+            for (int c = tid; c < kFW * (TX + 4); c += NT) {
+                const int r = c / (TX + 4), cc = c - r * (TX + 4);
                 double acc = 0.0;
 #pragma unroll
                 for (int l = -2; l <= 2; l++) acc += raw[r][cc + 2 + l] * g.t[l + 2];
                 hs[r][cc] = acc;
             }
         } else {
-            for (int c = tid; c < kFW * (kFT + 4); c += 256) {
-                const int r = c / (kFT + 4), cc = c - r * (kFT + 4);
+            for (int c = tid; c < kFW * (TX + 4); c += NT) {
+                const int r = c / (TX + 4), cc = c - r * (TX + 4);
                 const int i = ib - kFH + r, j = j0 - 2 + cc;
                 if (i < 0 || i >= H || j < 0 || j >= W) continue;
                 double acc = 0.0;
@@ -1176,9 +1181,9 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
         // -- P3: vertical pass, blend and imdt on (ib - 2 .. ib + 17) x (j0 - 2 .. j0 + 17)
 #pragma unroll
         for (int q = 0; q < kP3; q++) {
-            const int c = tid + q * 256, r = c / (kFT + 4), cc = c - r * (kFT + 4);
+            const int c = tid + q * NT, r = c / (TX + 4), cc = c - r * (TX + 4);
             const int i = ib - 2 + r, j = j0 - 2 + cc;
-            if (c >= (kFT + 4) * (kFT + 4) || i < 0 || i >= H || j < 0 || j >= W) continue;
+            if (c >= (kFT + 4) * (TX + 4) || i < 0 || i >= H || j < 0 || j >= W) continue;
             double s2 = 0.0;
             if (interior) {
 #pragma unroll
@@ -1192,7 +1197,7 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
             t *= 0.4;
             t += s2 * 0.6;
             bl[r][cc] = t;
-            if (r >= 2 && r < kFT + 2 && cc >= 2 && cc < kFT + 2) it[r - 2][cc - 2] = s2 - s1;
+            if (r >= 2 && r < kFT + 2 && cc >= 2 && cc < TX + 2) it[r - 2][cc - 2] = s2 - s1;
         }
         if (k + 1 < PLANES) load_s1(k + 1);
         __syncthreads();
@@ -1292,18 +1297,19 @@ __global__ __launch_bounds__(256) void k_flow_system(const double* __restrict__ 
     double2s* const pc = reinterpret_cast<double2s*>(out.q[4]);
     __syncthreads();
     // ---- written in skew order, as k_assemble_skew does: a group of 16 threads stores 16 neighbouring rows of one position
-    const int grp = tid / kFT, jj = tid - grp * kFT;
-    const int j = j0 + jj;
+    // (a tile of TX columns is TX / 16 sub-tiles of 16 x 16 cells: 16 groups of 16 threads each, as for TX = 16)
+    const int g16 = tid / kFT, jj = tid - g16 * kFT, sub = g16 % (TX / kFT), grp = g16 / (TX / kFT);
+    const int col = sub * kFT + jj, j = j0 + col;
     if (j >= W) return;
-    for (int pp = grp; pp <= 2 * kFT - 2; pp += 256 / kFT) {
+    for (int pp = grp; pp <= 2 * kFT - 2; pp += kFT) {
         const int r = pp - jj;
         if (r < 0 || r >= kFT) continue;
         const int i = ib + r;
         if (i >= row1) continue;
         const size_t q = skew_cell(i, j, sk);
-        pa[q] = double2s{stage[0][r][jj], stage[1][r][jj]};
-        pb[q] = double2s{stage[2][r][jj], stage[3][r][jj]};
-        pc[q] = double2s{stage[4][r][jj], stage[5][r][jj]};
+        pa[q] = double2s{stage[0][r][col], stage[1][r][col]};
+        pb[q] = double2s{stage[2][r][col], stage[3][r][col]};
+        pc[q] = double2s{stage[4][r][col], stage[5][r][col]};
     }
 }
 
@@ -1913,15 +1919,24 @@ int flow_system(papof_handle* h, const double* im1, const double* im2, const dou
     if (row1 < 0) row1 = H;
     if (row0 < 0 || row1 > H) return PAPOF_EINVAL;
     if (row1 <= row0) return PAPOF_OK;
-    const int ntiles = ((W + kFT - 1) / kFT) * ((row1 - row0 + kFT - 1) / kFT);
+    // tile width: 16 columns (256 threads) or 32 (512 threads: 1.875 instead of 2.25 warped pixels per cell, two slots of taps
+    // and gathers per thread instead of three) -- PAPOF_FS_TX, read once per process (an A/B switch; both forms give the same bits)
+    static const int tx_env = std::getenv("PAPOF_FS_TX") ? std::atoi(std::getenv("PAPOF_FS_TX")) : 0;
+    const int TXr = tx_env == 32 ? 32 : (tx_env == 16 ? 16 : kFlowSystemTX);
+    const int ntiles = ((W + TXr - 1) / TXr) * ((row1 - row0 + kFT - 1) / kFT);
     const dim3 grid(8 * ((ntiles + 7) / 8), batch);  // (the kernel maps block -> tile: a contiguous run of tiles per XCD)
     const SixPlanes six{{out.phi, out.xy, out.a1, out.a2, out.b1, out.b2}};
     const BatchK bk0{0, 0, 0, 0, 0, 0};
-    const auto kern = batch > 1 ? (out.skew ? (planes == 5 ? k_flow_system<5, true, true> : k_flow_system<3, true, true>)
-                                            : (planes == 5 ? k_flow_system<5, false, true> : k_flow_system<3, false, true>))
-                                : (out.skew ? (planes == 5 ? k_flow_system<5, true> : k_flow_system<3, true>)
-                                            : (planes == 5 ? k_flow_system<5, false> : k_flow_system<3, false>));
-    hipLaunchKernelGGL(kern, grid, dim3(256), 0, h->stream, im1, im2, u, v, im1s, H, W, alpha, omega,
+    const auto kern16 = batch > 1 ? (out.skew ? (planes == 5 ? k_flow_system<5, true, true> : k_flow_system<3, true, true>)
+                                              : (planes == 5 ? k_flow_system<5, false, true> : k_flow_system<3, false, true>))
+                                  : (out.skew ? (planes == 5 ? k_flow_system<5, true> : k_flow_system<3, true>)
+                                              : (planes == 5 ? k_flow_system<5, false> : k_flow_system<3, false>));
+    const auto kern32 = batch > 1 ? (out.skew ? (planes == 5 ? k_flow_system<5, true, true, 32> : k_flow_system<3, true, true, 32>)
+                                              : (planes == 5 ? k_flow_system<5, false, true, 32> : k_flow_system<3, false, true, 32>))
+                                  : (out.skew ? (planes == 5 ? k_flow_system<5, true, false, 32> : k_flow_system<3, true, false, 32>)
+                                              : (planes == 5 ? k_flow_system<5, false, false, 32> : k_flow_system<3, false, false, 32>));
+    const auto kern = TXr == 32 ? kern32 : kern16;
+    hipLaunchKernelGGL(kern, grid, dim3(TXr * kFT), 0, h->stream, im1, im2, u, v, im1s, H, W, alpha, omega,
                        out.skew ? skew_idx(out) : SkewIdx{0, 0, 0, 0, 0, 0, 0, 0, 0}, six, smooth5_taps(), deriv5_taps(),
                        take_stamp(h), wit, 2e-20 * (double)H * (double)W, h->lap_epoch, row0, row1, bk ? *bk : bk0);
     LAUNCH_CHECK();

@@ -128,6 +128,7 @@ struct ExactArgs {
     // BATCHED solves (api.hip: flow_batch): blockIdx.y is the frame pair; its operands are the first pair's advanced by these
     // strides -- doubles between the pairs' coefficient planes / (du, dv) planes, unsigneds between their counters.  0: one solve.
     size_t bs_coef, bs_d, bs_prog;
+    int skip_dead;  // lanes whose image row lies outside [0, H) for the whole task neither load nor store (k_sor_exact, below)
 };
 
 __device__ __forceinline__ void stamp_now(unsigned long long* s) {
@@ -514,11 +515,22 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A_in) {
     L.pos_c = (unsigned)A.hp * 16u;
     L.pos_d = (unsigned)A.nb * kBlock;
     const unsigned base = ((unsigned)(r0 + A.qt) * (unsigned)A.hp + (unsigned)(r0 + A.rt) + lane) * 16u;
-    L.pa = base;
-    L.pbc = ghost ? kOob : base;
+    // DEAD lanes (round 4): a lane stands for ONE image row during its whole task; where that row lies outside the image --
+    // the top band's first k + 1 lanes at sweep k, the last band's lanes beyond row H - 1 -- every operand it would load is a
+    // non-cell (0.0 by the layout's contract) or a zero it stored itself, and nobody but another dead lane reads what it stores.
+    // Its accesses are switched off like a ghost lane's coefficients (kOob: the load returns 0.0, the store is dropped, no line is
+    // touched): 9 % (1440x810) to 13 % (1080x607) of a level's lanes.  The one thing that can differ is the SIGN of a zero a
+    // dead lane used to store ((1 - omega) * 0 + 0 * x) and a live neighbour multiplies by a weight and adds to a sum -- which
+    // changes nothing unless that sum is itself an exact zero of the opposite sign; the full-array SHA-256 comparisons with the
+    // reference's goldens and the bit-for-bit tests against the oracle hold on every shape tested.  PAPOF_SOR_DEAD=0 restores
+    // the loads and stores (A/B).  Not in SPLIT launches (the inbox cells of a cut are always exchanged).
+    const int row = r0 + (int)lane;
+    const bool dead = !SPLIT && A.skip_dead != 0 && (row < 0 || row >= A.H);
+    L.pa = dead ? kOob : base;
+    L.pbc = (ghost || dead) ? kOob : base;
     // (du, dv): the writer of step s uses position s + 1 (position 0 is never written: the centre before step 0)
     const unsigned mine = (unsigned)(k & 1) * par_bytes, prev = (unsigned)((k + 1) & 1) * par_bytes;
-    L.st = mine + L.pos_d + (unsigned)b * kBlock + lane * 16u;
+    L.st = dead ? kOob : mine + L.pos_d + (unsigned)b * kBlock + lane * 16u;
     // lanes >= 1: own block, cell lane - 1; lane 0: the row above, NEW value: block b-1, cell 62, written by (b-1, k) 63
     // steps ahead of ours.  (Selects, not branches: a divergent branch anywhere makes the compiler structurise the kernel.)
     // (SPLIT, first band below a cut: the inbox cell of this sweep -- see ExactArgs -- instead of cell 62)
@@ -529,7 +541,7 @@ __global__ __launch_bounds__(64) void k_sor_exact(ExactArgs A_in) {
     T.rd2 = __builtin_amdgcn_make_buffer_rsrc((void*)((SPLIT && A.peer_du) ? A.peer_du : A.du), 0, 2u * par_bytes, 0x00020000);
     // Sweep 0 reads du = dv = 0 (src/OpticalFlow.cpp:452-453) as out-of-range offsets, not from memory: the planes need
     // no clearing between solves except for the tail positions no task writes (sor_solve clears them anyway: cache warming).
-    L.pd = lane == 0 ? pd_above : (k > 0 ? prev + L.pos_d + (unsigned)b * kBlock + (lane - 1u) * 16u : kOob);
+    L.pd = dead ? kOob : (lane == 0 ? pd_above : (k > 0 ? prev + L.pos_d + (unsigned)b * kBlock + (lane - 1u) * 16u : kOob));
     const double om1 = ghost ? 1.0 : A.om1;  // ghost lanes pass their centre value through unchanged
 
     // one 128-byte line per counter: hundreds of waves publish and poll concurrently, and counters sharing a
@@ -866,6 +878,8 @@ __global__ __launch_bounds__(64) void k_sor_fused(ExactArgs A) {
     const unsigned pd1 = b > 0 ? mine + 63u * L.pos_d + (unsigned)(b - 1) * kBlock + 62u * 16u : kOob;
     const unsigned pd0 = b > 0 ? mine + 65u * L.pos_d + (unsigned)(b - 1) * kBlock + 61u * 16u : kOob;
     const unsigned pd_own = q > 0 ? prev + 2u * L.pos_d + (unsigned)b * kBlock + (lane - 2u) * 16u : kOob;  // pair 0: zeros
+    // [dead lanes as in k_sor_exact were tried here and taken out: the level-0 solve is bound by its chain, not by bytes, and the
+    // three extra selects of the set-up changed the kernel's register allocation -- 964 instead of 917 us per solve, switch on or off]
     L.pd = lane == 0 ? pd0 : (lane == 1 ? pd1 : pd_own);
     FLane F;
     const bool real1 = lane >= 2 && lane <= kLanes - 2;
@@ -2172,6 +2186,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         A.peer_du = nullptr;
         A.peer_prog = nullptr;
         A.top_cut = A.bot_cut = 0;
+        A.skip_dead = h->sor_skip_dead;
         A.bs_coef = bt ? bt->coef : 0;
         A.bs_d = bt ? bt->d : 0;
         A.bs_prog = bt ? bt->prog : 0;
@@ -2481,6 +2496,7 @@ int sor_solve_bands(papof_handle* h, const SorPlanes& sp, int H, int W, double a
     A.dbg = nullptr;
     A.stamp = nullptr;
     A.bs_coef = A.bs_d = A.bs_prog = 0;
+    A.skip_dead = h->sor_skip_dead;
     A.peer_du = split ? split->peer_du : nullptr;
     A.peer_prog = split ? split->peer_prog : nullptr;
     A.top_cut = split && split->top_cut ? 1 : 0;

@@ -86,23 +86,30 @@ def main():
     m = min(n, nb)  # ranks with bands: 0 .. m - 1
     du, dv = np.zeros((h, w)), np.zeros((h, w))
     msgs = 0
-    inbox = None
-    if mine and B0 > 0:  # all K rows from the rank above, once it has finished (the staged protocol)
-        t = torch.zeros(K, 2, w, dtype=torch.float64)
-        dist.recv(t, src=rank - 1)
-        inbox = t.numpy()
-        msgs += 1
-    outbox = np.zeros((K, 2, w))
-    if mine:
-        for k in range(K):
+    # Ranges of sweeps (PAPOF_BANDS_CHUNKS of bands_flow; sys.argv[5], default 1 = the ranks take turns): per range, receive
+    # the range's rows from the rank above, run the own rows for those sweeps, send the own last row of each sweep to the rank
+    # below -- rank g + 1 works on range c while rank g works on range c + 1 (blocking sends and receives between processes).
+    chunks = max(1, min(int(sys.argv[5]) if len(sys.argv) > 5 else 1, K))
+    for c in range(chunks):
+        k0, k1 = K * c // chunks, K * (c + 1) // chunks
+        if k1 <= k0 or not mine:
+            continue
+        inbox = None
+        if B0 > 0:
+            t = torch.zeros(k1 - k0, 2, w, dtype=torch.float64)
+            dist.recv(t, src=rank - 1)
+            inbox = t.numpy()
+            msgs += 1
+        outbox = np.zeros((k1 - k0, 2, w))
+        for k in range(k0, k1):
             up = BR * B0 - k - 1  # the row above the range: its sweep-k value comes from the rank above
             if inbox is not None and 0 <= up < h:
-                du[up], dv[up] = inbox[k, 0], inbox[k, 1]
+                du[up], dv[up] = inbox[k - k0, 0], inbox[k - k0, 1]
             r0, r1 = max(0, BR * B0 - k), min(h, BR * B1 - k)
             sweep_rows(P, du, dv, r0, r1, alpha, omega, h, w)
             last = BR * B1 - k - 1  # what the rank below needs of this sweep
             if 0 <= last < h:
-                outbox[k, 0], outbox[k, 1] = du[last], dv[last]
+                outbox[k - k0, 0], outbox[k - k0, 1] = du[last], dv[last]
         if rank + 1 < m:
             dist.send(torch.from_numpy(outbox), dst=rank + 1)
             msgs += 1

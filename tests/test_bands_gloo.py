@@ -22,19 +22,21 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("h,w,n_sor,world", [(150, 23, 7, 2), (200, 17, 5, 3), (260, 12, 9, 4), (70, 31, 4, 4),
-                                              (130, 9, 70, 2)])
-def test_exact_order_band_split_over_gloo(h, w, n_sor, world):
+@pytest.mark.parametrize("h,w,n_sor,world,chunks", [(150, 23, 7, 2, 1), (200, 17, 5, 3, 1), (260, 12, 9, 4, 1), (70, 31, 4, 4, 1),
+                                                     (130, 9, 70, 2, 1), (200, 17, 6, 3, 3), (150, 23, 7, 2, 64)])
+def test_exact_order_band_split_over_gloo(h, w, n_sor, world, chunks):
+    """chunks > 1: the staged protocol in ranges of sweeps (PAPOF_BANDS_CHUNKS of bands_flow) -- the rows of a range travel as soon
+    as the range is done, the ranks work on different ranges at the same time; same bits, `chunks` messages per cut."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "_bands_gloo_worker.py")] + [str(x) for x in (h, w, n_sor, 11 * h + w)]
+           os.path.join(ROOT, "tests", "_bands_gloo_worker.py")] + [str(x) for x in (h, w, n_sor, 11 * h + w, chunks)]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     m = re.search(r"BANDS_GLOO ok=(\d) messages=(\d+) ranks_with_bands=(\d+)", out.stdout)
     assert m, out.stdout + out.stderr[-2000:]
     assert m.group(1) == "1", out.stdout
-    assert int(m.group(2)) == 2 * (int(m.group(3)) - 1)  # one message per cut (counted at both ends)
+    assert int(m.group(2)) == 2 * (int(m.group(3)) - 1) * min(chunks, n_sor)  # one message per cut and range (counted at both ends)
 
 
 @pytest.mark.parametrize("h,w,n_sor,n", [(1080, 1920, 30, 8), (1080, 1920, 30, 2), (341, 607, 42, 8), (135, 240, 30, 8),

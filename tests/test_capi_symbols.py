@@ -94,3 +94,29 @@ def test_collection_in_flight_policy_and_setter_arguments(lib):
     assert lib.papof_set_stream_overlap(None, 0) == capi.EINVAL if hasattr(capi, "EINVAL") else lib.papof_set_stream_overlap(None, 0) != 0
     out = (capi.c_int * 4)()
     assert lib.papof_lap_guard_stats(None, out) != 0
+
+
+def test_rccl_standin_builds_loads_and_exports_the_api_the_transport_binds():
+    """tests/fake_rccl (TEST infrastructure: the stand-in for librccl behind PAPOF_RCCL_LIB): the library must load without a GPU
+    and export every entry point csrc/tiles.hip looks up (rccl(): PAPOF_SYM), plus the hooks the GPU tests read.  No call that
+    touches a device is made here."""
+    import ctypes
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(so)])
+    lib = ctypes.CDLL(so)
+    for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommAbort", "ncclCommCount", "ncclCommUserRank",
+                "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclGetErrorString", "fake_rccl_error_count",
+                "fake_rccl_error_kinds", "fake_rccl_reset_errors", "fake_rccl_stats", "fake_rccl_identity"):
+        assert hasattr(lib, sym), sym
+    lib.fake_rccl_identity.restype = ctypes.c_char_p
+    assert b"fake rccl" in lib.fake_rccl_identity()
+    # the product library must not depend on it (it is dlopen'ed by path, on request only)
+    out = subprocess.run(["ldd", os.path.join(root, "papteam_opticalflow_amd", "csrc", "libpapof.so")], capture_output=True, text=True)
+    assert "fake_rccl" not in out.stdout
+    # grouping without a device: nested starts / ends balance, an unbalanced end is refused
+    assert lib.ncclGroupStart() == 0 and lib.ncclGroupStart() == 0 and lib.ncclGroupEnd() == 0 and lib.ncclGroupEnd() == 0
+    assert lib.ncclGroupEnd() != 0

@@ -7,6 +7,7 @@ fp64 operation order without FMA contraction, so the tests demand far more: TOL 
 1e-9 for whole solves (chaotic amplification of a last-bit difference through 45+ outer iterations stays orders
 of magnitude below that); bit-for-bit equality is reported when it holds.
 """
+import hashlib
 import json
 import os
 
@@ -20,6 +21,7 @@ pytestmark = pytest.mark.gpu
 TOL_STAGE = 1e-12
 TOL_SOLVE = 1e-9
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -784,3 +786,36 @@ def test_laplacian_noise_guard_never_reruns_ordinary_input(kind):
             assert not r1[0].any() and not r1[1].any()
     finally:
         g.close()
+
+
+def test_flow_system_tile_widths_give_the_same_bits(gpu):
+    """k_flow_system's tile is 16 rows x TX columns, TX = 16 (256 threads) or 32 (512 threads; PAPOF_FS_TX, read once per process:
+    hence child processes).  Same operations per cell, so the same bits: whole calls on ragged sizes (tiles cut at both borders),
+    gray frames, the row-major form of the small levels, against THIS process's results (which the other tests pin)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, hashlib, numpy as np
+sys.path[:0] = [%r, %r, %r]
+import cases
+from papteam_opticalflow_amd import Papof
+g = Papof(0)
+for res, h, w, lv, gray in (("240", 135, 240, 3, 0), ("240", 101, 173, 3, 0), ("480", 270, 480, 4, 0), ("480", 203, 311, 2, 1), ("240", 37, 53, 2, 0)):
+    a, b = cases.load_pair(res)
+    a, b = np.ascontiguousarray(a[:h, :w]), np.ascontiguousarray(b[:h, :w])
+    if gray:
+        a, b = np.ascontiguousarray(a[..., :1]), np.ascontiguousarray(b[..., :1])
+    out = g.coarse2fine_flow(a, b, lv)[:3]
+    print(res, h, w, lv, gray, " ".join(hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest()[:16] for x in out))
+''' % (ROOT, os.path.join(ROOT, "tests"), GOLD)
+    outs = {}
+    for tx in ("16", "32"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, PAPOF_FS_TX=tx))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tx] = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(outs[tx]) == 5, r.stdout
+    assert outs["16"] == outs["32"], (outs["16"], outs["32"])
+    a, b = cases.load_pair("240")
+    here = gpu.coarse2fine_flow(a, b, 3)[:3]
+    assert outs["32"][0].split()[5:] == [hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest()[:16] for x in here]
