@@ -340,7 +340,16 @@ int flow_batch_host(papof_handle* h, int n_pairs, int sequence, const void* cons
         }
     }
     BatchOut out;
-    PAPOF_TRY(flow_batch_device(h, n_pairs, sequence, frames, u8, H, W, C, levels, P, tm, out));
+    {
+        const int rc = flow_batch_device(h, n_pairs, sequence, frames, u8, H, W, C, levels, P, tm, out);
+        if (rc == PAPOF_ENOMEM) {  // no room for the arrays of a batch on this device: the pairs one after the other
+            std::memset(tm, 0, sizeof tm);
+            for (int p = 0; p < n_pairs; p++) PAPOF_TRY(single(p));
+            if (timing_sec) std::memcpy(timing_sec, tm, sizeof tm);
+            return PAPOF_OK;
+        }
+        PAPOF_TRY(rc);
+    }
     const size_t np0 = (size_t)H * W;
     // Result arrays laid out as the device's ([pair][vx, vy][H x W] and [pair][H x W x c] in one block each -- what the Python
     // binding allocates, page-locked) come back as TWO copies; anything else as three per pair.

@@ -40,5 +40,25 @@ for res, levels, kw in (("1920", 5, dict(n_outer=3, n_outer_per_level=0, n_sor=3
             stop = True
             th.join()
         print("%s L%d %-22s %d calls, %.1f ms each, mismatches so far %d" % (res, levels, phase, n, (time.perf_counter() - t0) / n * 1e3, bad), flush=True)
+# batches (csrc/batch.hip): 16 consecutive 240x135 pairs per launch chain, alone and beside the other handle
+v = [np.ascontiguousarray(np.roll(cases.load_frame_u8("240", 1 + i % 2), (i // 2) * 3, axis=1)) for i in range(17)]
+ref = [tuple(x.copy() for x in o) for o in g.flow_batch(v, 5)[0]]
+for phase in ("alone", "beside another handle"):
+    th = None
+    if phase != "alone":
+        stop = False
+        th = threading.Thread(target=hammer)
+        th.start()
+    t0 = time.perf_counter()
+    nb = max(1, n // 4)
+    for it in range(nb):
+        out = g.flow_batch(v, 5)[0]
+        if not all(np.array_equal(x, y) for o, r in zip(out, ref) for x, y in zip(o, r)):
+            bad += 1
+            print("MISMATCH batch", phase, it, flush=True)
+    if th:
+        stop = True
+        th.join()
+    print("batch of 16 x 240x135 L5 %-22s %d batches, %.2f ms per pair, mismatches so far %d" % (phase, nb, (time.perf_counter() - t0) / nb / 16 * 1e3, bad), flush=True)
 print("guard stats", g.lap_guard_stats())
 sys.exit(1 if bad else 0)
