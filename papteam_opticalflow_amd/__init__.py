@@ -134,10 +134,10 @@ def collection_in_flight(height, width):
 def collection_batch(height, width):
     """Pairs per launch chain flow_collection() uses by default (0: unbatched): frames too small to fill the chip share every
     launch (csrc/batch.hip) -- 240x135 on the reference schedule: 8.3 ms per single call, 2.2 ms per pair as 16 independent calls in
-    flight, 0.8 / 0.65 ms per pair in batches of 16 / 32 (tools/batch_probe.py, profiles/r04_batch_probe_*.txt)."""
+    flight, 0.72 / 0.58 ms per pair in batches of 16 / 32 (0.48 with two chains in flight) (tools/batch_probe.py, profiles/r04_batch_probe_*.txt)."""
     mpix = height * width / 1e6
     # measured per pair, reference schedule, host uint8 in / float64 out (profiles/r04_batch_probe_*.txt, r04_collection_probe_*):
-    # 240x135: 8.3 ms alone, 2.2 as 16 calls in flight, 0.79 / 0.65 in batches of 16 / 32; 480x270: 11.7 / 3.25 / 2.2 in batches of
+    # 240x135: 8.3 ms alone, 2.2 as 16 calls in flight, 0.72 / 0.58 in batches of 16 / 32; 480x270: 11.7 / 3.25 / 2.0 in batches of
     # 16; 960x540: 16.5 / 8.9 / 9.2 in batches of 8 -- from there on a pair fills enough of the chip by itself
     return 32 if mpix <= 0.05 else (16 if mpix <= 0.14 else 0)
 

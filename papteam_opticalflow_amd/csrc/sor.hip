@@ -1831,6 +1831,7 @@ int sor_redblack_halfsweep(papof_handle* h, const SorPlanes& sp, int H, int W, d
 // margin is for whatever else runs beside the solve); larger solves become consecutive launches over ranges of sweeps --
 // the ping-pong planes and the counters carry the state across the launch boundary.  PAPOF_SOR_RESIDENT (read when the
 // handle is created) overrides the bound: the tests use it to force many launches per solve.
+static int fill_pairs(papof_handle* h, void* base, size_t stride_bytes, size_t bytes, int batch);  // (defined with the strips' helpers below)
 static int resident_tasks(const papof_handle* h) {
     if (h->sor_resident > 0) return h->sor_resident;
     return std::max(64, (h->cu_count > 0 ? h->cu_count : 256) * 8);
@@ -2205,7 +2206,7 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
         static const char* const clear_env = std::getenv("PAPOF_SOR_CLEAR");
         static const bool clear_tail_only = clear_env && std::strcmp(clear_env, "tail") == 0;
         if (bt) {  // every pair's two planes in one fill node (the pairs' planes lie bt->d doubles apart)
-            PAPOF_HIP(hipMemset2DAsync(sp.du, bt->d * sizeof(double), 0, sd.nd * 16, (size_t)batch, h->stream));
+            PAPOF_TRY(fill_pairs(h, sp.du, bt->d * sizeof(double), sd.nd * 16, batch));
         } else if (sd.group > 1 || !clear_tail_only) {
             PAPOF_HIP(hipMemsetAsync(sp.du, 0, (sd.nd + sd.nh) * 16, h->stream));  // both planes (+ the halo rows)
         } else {
@@ -2389,6 +2390,22 @@ int sor_solve(papof_handle* h, const SorPlanes& sp, int H, int W, double alpha, 
 // before the strips below it have even been launched, the counters of a solve must be zero before its FIRST strip
 // starts: every solve of a level has its own counter array, all cleared at once by sor_strips_begin() before the
 // streams fork.  The (du, dv) blocks of the strip's bands are cleared by the strip itself (cache warming, sor_solve).
+// Zero n16 16-byte cells of every pair of a batch (the pairs' blocks lie stride16 cells apart): blockIdx.y = pair.  The runtime's
+// 2-D fill reaches 0.75 TB/s on these shapes (43 MB in 58 us: profiles/r04_batch16_kernel_avgs_by_grid_xcd_affine.txt); this one
+// is a plain streaming store.
+__global__ __launch_bounds__(256) void k_fill_pairs(uint4* __restrict__ d, size_t stride16, size_t n16) {
+    uint4* const p = d + (size_t)blockIdx.y * stride16;
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < n16; c += (size_t)gridDim.x * 256) p[c] = uint4{0u, 0u, 0u, 0u};
+}
+static int fill_pairs(papof_handle* h, void* base, size_t stride_bytes, size_t bytes, int batch) {
+    if ((stride_bytes | bytes | (size_t)(uintptr_t)base) & 15) return PAPOF_EINVAL;
+    const size_t n16 = bytes / 16;
+    const unsigned gx = (unsigned)std::min<size_t>((n16 + 1023) / 1024, 2048);  // four cells per thread and more on big planes
+    hipLaunchKernelGGL(k_fill_pairs, dim3(std::max(1u, gx), batch), dim3(256), 0, h->stream, (uint4*)base, stride_bytes / 16, n16);
+    PAPOF_HIP(hipGetLastError());
+    return PAPOF_OK;
+}
+
 __global__ void k_sor_clear_bands(uint4* __restrict__ d, int nb, int b0, int nbl, unsigned n16) {
     // the 16-byte cells [position][band b0 .. b0+nbl-1][64] of both parities; n16 = positions * nbl * 64
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2564,8 +2581,7 @@ int sor_reset_planes(papof_handle* h, const SorPlanes& sp) {
 // ... of every pair of a batch at once: the pairs' operand blocks lie `stride` doubles apart (api.hip / batch.hip: flow_batch)
 int sor_reset_planes_batch(papof_handle* h, const SorPlanes& sp, int batch, size_t stride) {
     if (!sp.skew) return PAPOF_OK;
-    PAPOF_HIP(hipMemset2DAsync(sp.phi, stride * sizeof(double), 0, 3 * plane_pitch(sp.sd) * sizeof(double), (size_t)batch, h->stream));
-    return PAPOF_OK;
+    return fill_pairs(h, sp.phi, stride * sizeof(double), 3 * plane_pitch(sp.sd) * sizeof(double), batch);
 }
 
 // Sweeps per workgroup of the exact-order solver for this problem: the grouped kernel needs the verified DPP lane
