@@ -158,7 +158,8 @@ def flow_collection(frames, pyramidLevels, in_flight=None, device=None, on_pair=
     batch: pairs per launch chain (default by frame size, collection_batch(); 0 / 1: every pair its own call).  Small frames
     cannot fill the chip and are bound by the device's dispatch of their ~210 little dependent kernels per pair; in a batch
     every launch serves all its pairs (include/papof.h: papof_flow_batch*).  With batch > 1 the ten timers of a pair are its
-    CHAIN's (Total = wall time of the chain, Phase5_SOR = its solver kernels)."""
+    equal SHARE of its chain's (Total = wall time of the chain / its pairs, Phase5_SOR = its solver kernels / its pairs; the
+    other phases are not separated in a batch), so that the reference's per-pair timing file still adds up."""
     import threading
     import numpy as np
     capi.load()  # once, in this thread
@@ -241,7 +242,7 @@ def _flow_collection_batched(frames, levels, batch, in_flight, device, on_pair, 
                     nxt[0] += 1
                 reuse = out if (on_pair is not None and out is not None and len(out) == i1 - i0) else None
                 out, t = pool[s].flow_batch(frames[i0:i1 + 1], levels, params, sequence=True, out=reuse)
-                timing = capi.format_timing(t)
+                timing = capi.format_timing(t / (i1 - i0))  # a pair's share of its chain: sums over a collection stay meaningful
                 for j in range(i1 - i0):
                     if on_pair is not None:
                         on_pair(i0 + j, timing, *out[j])
