@@ -158,7 +158,12 @@ int flow_batch_device(papof_handle* h, int B, int sequence, const void* const* f
             PAPOF_HIP(hipMemcpyAsync(stage + (size_t)f * frame_bytes, frames[f], frame_bytes, hipMemcpyHostToDevice, st));
     }
     if (prog_total && !sor_counters_clear(h, 0, prog_total)) return PAPOF_EDEVICE;
-    const unsigned epoch = ++h->lap_epoch;  // a flag is set when it holds this call's number
+    if (++h->lap_epoch >= kLapNone) {  // (2^31 passes later: start over on cleared flags, as flow_device does -- the handle's own
+        // flag block holds pass numbers that are never cleared otherwise, and `epoch ^ kLapNone` must not be 0)
+        if (h->lap_flags_dev) PAPOF_HIP(hipMemsetAsync(h->lap_flags_dev, 0, kLapFlagWords * sizeof(unsigned), st));
+        h->lap_epoch = 1u;
+    }
+    const unsigned epoch = h->lap_epoch;  // a flag is set when it holds this call's number
     if (guard) {
         PAPOF_HIP(hipMemsetAsync(wit, 0, (size_t)B * kLapFlagWords * sizeof(unsigned), st));
         PAPOF_HIP(hipMemsetAsync(nzf, 0, (size_t)nF * kLapNzWords * sizeof(unsigned), st));
