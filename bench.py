@@ -574,7 +574,7 @@ def main():
                     dt = time.perf_counter() - th
                     assert sorted(seen) == list(range(npairs))
                     out["collection_u8_batches_of_%d" % nb_] = {
-                        "pairs": npairs, "batch": nb_, "chains_in_flight": 2, "ms_per_pair": round(dt / npairs * 1e3, 3),
+                        "pairs": npairs, "batch": nb_, "chains_in_flight": 3, "ms_per_pair": round(dt / npairs * 1e3, 3),
                         "value": round(npairs * h * w / 1e6 / dt, 2), "unit": "Mpix/s",
                         "note": "flow_collection(batch=%d): %d consecutive pairs per launch chain (papof_flow_batch_u8), host uint8 "
                                 "frames in, float64 results out (PCIe-inclusive); every pair bit-identical to the single call" % (nb_, nb_)}

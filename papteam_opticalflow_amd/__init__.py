@@ -215,13 +215,16 @@ def flow_collection(frames, pyramidLevels, in_flight=None, device=None, on_pair=
 
 def _flow_collection_batched(frames, levels, batch, in_flight, device, on_pair, solver):
     """flow_collection() through papof_flow_batch*: the pairs of a collection in chains of `batch` consecutive pairs per launch
-    chain (a video: every frame's pyramid is built once per chain), `in_flight` chains at a time (default 2: one handle's uploads,
-    downloads and host work beside the other's kernels).  Bit-identical results, pair for pair."""
+    chain (a video: every frame's pyramid is built once per chain), `in_flight` chains at a time (default 3: one handle's uploads,
+    downloads and host work beside the others' kernels).  Bit-identical results, pair for pair."""
     import os
     import threading
     n_pairs = len(frames) - 1
     dev = int(os.environ.get("PAPOF_DEVICE", "0")) if device is None else int(device)
-    k = max(1, min(int(in_flight) if in_flight else 2, (n_pairs + batch - 1) // batch))
+    # chains in flight: 240x135 in batches of 32: 0.58 / 0.43 / 0.40 / 0.39 / 0.49 ms per pair with 1 / 2 / 3 / 4 / 6
+    # (tools/collection_chains_probe.py, profiles/r04_collection_chains_probe.txt): one chain's uploads, downloads, host work and
+    # one-workgroup solves of its smallest levels beside the others' kernels
+    k = max(1, min(int(in_flight) if in_flight else 3, (n_pairs + batch - 1) // batch))
     pool = _collection_handles.setdefault(dev, [])
     while len(pool) < k:
         pool.append(Papof(dev))
